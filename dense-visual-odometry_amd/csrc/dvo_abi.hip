@@ -1,0 +1,781 @@
+// C ABI of the MI355X direct-alignment core (see include/dvo_hip.h for the contract and the
+// reference interfaces each entry point replaces).  Host-side only: context, device memory, launches.
+#include "../../include/dvo_hip.h"
+#include "dvo_internal.h"
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <vector>
+
+namespace {
+
+thread_local char g_create_error[512] = "";
+
+struct SlotInfo {
+    int w = 0, h = 0, levels = 0;
+    bool ready = false;
+};
+
+struct HostStage {          // pinned staging for the small per-call arrays
+    int* prev = nullptr;
+    int* cur = nullptr;
+    float* T = nullptr;
+    double* wparam = nullptr;
+    double* out = nullptr;          // [max_pairs][DVO_STRIDE]
+    double* xi = nullptr;           // [max_pairs][6]
+    int* iters = nullptr;
+    double* err = nullptr;
+};
+
+}  // namespace
+
+struct dvo_ctx {
+    int device = 0;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;
+    int max_w = 0, max_h = 0, max_levels = 0, n_slots = 0, max_pairs = 0;
+    size_t slot_stride = 0;
+    uint8_t* d_slots = nullptr;
+    std::vector<SlotInfo> slots;
+    // camera
+    bool have_camera = false;
+    float fx = 0, fy = 0, cx = 0, cy = 0, skew = 0;
+    double depth_scale = 0;
+    // scratch (device)
+    int* d_prev = nullptr;
+    int* d_cur = nullptr;
+    float* d_T = nullptr;
+    float* d_Tinit = nullptr;
+    double* d_wparam = nullptr;
+    int* d_active = nullptr;
+    double* d_partials = nullptr;
+    size_t partials_doubles = 0;
+    double* d_out = nullptr;
+    DvoPairState* d_state = nullptr;
+    double* d_xi = nullptr;
+    int* d_iters = nullptr;
+    double* d_err = nullptr;
+    uint8_t* d_stage_img = nullptr;      // staging for host->device image uploads (bgr needs 3 B/px + depth)
+    float* d_dense = nullptr;            // dense writer outputs: r[npix] J[6 npix] uv[2 npix] + valid
+    double* d_trace = nullptr;
+    int trace_cap = 0;
+    HostStage hs;
+    // profiling
+    bool profiling = false;
+    hipEvent_t ev_a = nullptr, ev_b = nullptr;
+    hipEvent_t tm_a = nullptr, tm_b = nullptr;
+    struct PendingEv { hipEvent_t a, b; int level; };
+    std::vector<PendingEv> pending;
+    std::vector<hipEvent_t> ev_pool;
+    int64_t prof_launches[DVO_MAX_LEVELS] = {0};
+    double prof_ms[DVO_MAX_LEVELS] = {0};
+    char err[512] = "";
+};
+
+namespace {
+
+int fail(dvo_ctx* ctx, int code, const char* fmt, ...)
+{
+    char* dst = ctx ? ctx->err : g_create_error;
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(dst, 512, fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define HIP_TRY(ctx, expr)                                                                              \
+    do {                                                                                                \
+        hipError_t _e = (expr);                                                                         \
+        if (_e != hipSuccess)                                                                           \
+            return fail(ctx, (_e == hipErrorOutOfMemory) ? DVO_ERR_OUT_OF_MEMORY : DVO_ERR_HIP,         \
+                        "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__);     \
+    } while (0)
+
+inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+// Layout of one frame slot for a w x h image: per level gray | depth | packed, each 256-byte aligned with
+// 64 bytes of slack so 8-byte vector loads of the last pixels stay inside the slot.
+void level_geometry(int w, int h, int levels, DvoLevelGeom* g, size_t* total)
+{
+    size_t off = 0;
+    int lw = w, lh = h;
+    for (int l = 0; l < levels; ++l) {
+        g[l].w = lw;
+        g[l].h = lh;
+        g[l].npix = lw * lh;
+        g[l].pitch = (int)align_up((size_t)lw + 2, 16);
+        g[l].off_gray = off;
+        off = align_up(off + (size_t)lw * lh + 64, 256);
+        g[l].off_depth = off;
+        off = align_up(off + (size_t)lw * lh * 2 + 64, 256);
+        g[l].off_packed = off;
+        off = align_up(off + (size_t)(lh + 1) * g[l].pitch * 4 + 64, 256);
+        lw = (lw + 1) / 2;
+        lh = (lh + 1) / 2;
+    }
+    if (total) *total = off;
+}
+
+// RGBDCameraModel.at (camera_model.py:62-79) in float32, and inv(K_L) as in oracle inverse_intrinsics
+DvoLevelCam level_camera(const dvo_ctx* c, int level)
+{
+    DvoLevelCam k;
+    if (level == 0) {
+        k.fx = c->fx; k.fy = c->fy; k.cx = c->cx; k.cy = c->cy; k.s = c->skew;
+    } else {
+        // scale_matrix (float32) @ K: entries sc*fx, sc*s, sc*cx + off*1, sc*fy, sc*cy + off
+        const float sc = (float)std::ldexp(1.0, -level);
+        const float off = (float)(std::ldexp(1.0, -level - 1) - 0.5);
+        k.fx = sc * c->fx;
+        k.s = sc * c->skew;
+        k.cx = sc * c->cx + off;
+        k.fy = sc * c->fy;
+        k.cy = sc * c->cy + off;
+    }
+    const volatile float one = 1.0f;
+    volatile float ia = one / k.fx;
+    volatile float id = one / k.fy;
+    volatile float ie = (-k.cy) / k.fy;
+    volatile float sd = k.s * id;
+    volatile float ib = (-sd) / k.fx;
+    volatile float se = k.s * ie;
+    volatile float t = (-se) - k.cx;
+    volatile float ic = t / k.fx;
+    k.ia = ia; k.ib = ib; k.ic = ic; k.id = id; k.ie = ie;
+    return k;
+}
+
+int check_slot(dvo_ctx* ctx, int slot, const char* what)
+{
+    if (slot < 0 || slot >= ctx->n_slots) return fail(ctx, DVO_ERR_INVALID_ARG, "%s: slot %d out of range [0,%d)", what, slot, ctx->n_slots);
+    if (!ctx->slots[slot].ready) return fail(ctx, DVO_ERR_BAD_STATE, "%s: slot %d holds no frame", what, slot);
+    return DVO_OK;
+}
+
+int check_pairs(dvo_ctx* ctx, int n_pairs, const int* prev_slot, const int* cur_slot, int level_needed, int* w, int* h)
+{
+    if (!ctx->have_camera) return fail(ctx, DVO_ERR_BAD_STATE, "camera not set (dvo_set_camera)");
+    if (n_pairs <= 0 || n_pairs > ctx->max_pairs) return fail(ctx, DVO_ERR_INVALID_ARG, "n_pairs %d outside [1,%d]", n_pairs, ctx->max_pairs);
+    if (!prev_slot || !cur_slot) return fail(ctx, DVO_ERR_INVALID_ARG, "null slot arrays");
+    for (int i = 0; i < n_pairs; ++i) {
+        int rc = check_slot(ctx, prev_slot[i], "prev");
+        if (rc) return rc;
+        rc = check_slot(ctx, cur_slot[i], "cur");
+        if (rc) return rc;
+        const SlotInfo& a = ctx->slots[prev_slot[i]];
+        const SlotInfo& b = ctx->slots[cur_slot[i]];
+        const SlotInfo& f = ctx->slots[prev_slot[0]];
+        if (a.w != f.w || a.h != f.h || b.w != f.w || b.h != f.h)
+            return fail(ctx, DVO_ERR_INVALID_ARG, "pair %d: frames of one call must share one size (%dx%d vs %dx%d)", i, a.w, a.h, f.w, f.h);
+        if (a.levels <= level_needed || b.levels <= level_needed)
+            return fail(ctx, DVO_ERR_INVALID_ARG, "pair %d: level %d not built (slots have %d/%d levels)", i, level_needed, a.levels, b.levels);
+    }
+    *w = ctx->slots[prev_slot[0]].w;
+    *h = ctx->slots[prev_slot[0]].h;
+    return DVO_OK;
+}
+
+int blocks_for(int npix) { return (npix + DVO_PX_PER_BLOCK - 1) / DVO_PX_PER_BLOCK; }
+
+hipEvent_t pool_event(dvo_ctx* ctx)
+{
+    if (!ctx->ev_pool.empty()) { hipEvent_t e = ctx->ev_pool.back(); ctx->ev_pool.pop_back(); return e; }
+    hipEvent_t e = nullptr;
+    if (hipEventCreate(&e) != hipSuccess) return nullptr;
+    return e;
+}
+
+void drain_profile(dvo_ctx* ctx)
+{
+    for (auto& pe : ctx->pending) {
+        float ms = 0.f;
+        if (hipEventSynchronize(pe.b) == hipSuccess && hipEventElapsedTime(&ms, pe.a, pe.b) == hipSuccess) {
+            ctx->prof_launches[pe.level] += 1;
+            ctx->prof_ms[pe.level] += ms;
+        }
+        ctx->ev_pool.push_back(pe.a);
+        ctx->ev_pool.push_back(pe.b);
+    }
+    ctx->pending.clear();
+}
+
+// one launch of the reduction kernel, optionally bracketed by events
+hipError_t launch_reduce_profiled(dvo_ctx* ctx, const DvoReduceParams& p, int level, int variant, int weight_mode, int scale_pass)
+{
+    hipEvent_t a = nullptr, b = nullptr;
+    if (ctx->profiling) {
+        if (ctx->pending.size() > 4096) drain_profile(ctx);
+        a = pool_event(ctx);
+        b = pool_event(ctx);
+        if (a && b) hipEventRecord(a, ctx->stream);
+    }
+    hipError_t e = dvo_launch_reduce(p, variant, weight_mode, scale_pass, ctx->stream);
+    if (ctx->profiling && a && b) {
+        hipEventRecord(b, ctx->stream);
+        ctx->pending.push_back({a, b, level});
+    }
+    return e;
+}
+
+int fill_reduce_params(dvo_ctx* ctx, int level, int n_pairs, int w, int h, DvoReduceParams* p)
+{
+    DvoLevelGeom g[DVO_MAX_LEVELS];
+    level_geometry(w, h, level + 1, g, nullptr);
+    p->slots = ctx->d_slots;
+    p->slot_stride = ctx->slot_stride;
+    p->g = g[level];
+    p->cam = level_camera(ctx, level);
+    p->depth_scale = ctx->depth_scale;
+    p->prev_slot = ctx->d_prev;
+    p->cur_slot = ctx->d_cur;
+    p->T = ctx->d_T;
+    p->wparam = ctx->d_wparam;
+    p->active = nullptr;
+    p->partials = ctx->d_partials;
+    p->blocks_per_pair = blocks_for(g[level].npix);
+    p->n_pairs = n_pairs;
+    if ((size_t)n_pairs * p->blocks_per_pair * DVO_STRIDE > ctx->partials_doubles)
+        return fail(ctx, DVO_ERR_INVALID_ARG, "internal: partial buffer too small");
+    return DVO_OK;
+}
+
+int build_pyramid_on_device(dvo_ctx* ctx, int slot, int w, int h, int levels)
+{
+    DvoLevelGeom g[DVO_MAX_LEVELS];
+    level_geometry(w, h, levels, g, nullptr);
+    uint8_t* base = ctx->d_slots + (size_t)slot * ctx->slot_stride;
+    for (int l = 0; l < levels; ++l) {
+        uint8_t* gray = base + g[l].off_gray;
+        uint16_t* depth = reinterpret_cast<uint16_t*>(base + g[l].off_depth);
+        uint32_t* packed = reinterpret_cast<uint32_t*>(base + g[l].off_packed);
+        if (l > 0) {
+            const uint8_t* pg = base + g[l - 1].off_gray;
+            const uint16_t* pd = reinterpret_cast<const uint16_t*>(base + g[l - 1].off_depth);
+            HIP_TRY(ctx, dvo_launch_median_down_u8(pg, g[l - 1].w, g[l - 1].h, gray, ctx->stream));
+            HIP_TRY(ctx, dvo_launch_median_down_u16(pd, g[l - 1].w, g[l - 1].h, depth, ctx->stream));
+        }
+        HIP_TRY(ctx, dvo_launch_sobel_pack(gray, g[l].w, g[l].h, packed, g[l].pitch, ctx->stream));
+    }
+    return DVO_OK;
+}
+
+int prepare_slot(dvo_ctx* ctx, int slot, int w, int h, int levels)
+{
+    if (slot < 0 || slot >= ctx->n_slots) return fail(ctx, DVO_ERR_INVALID_ARG, "slot %d out of range [0,%d)", slot, ctx->n_slots);
+    if (w <= 0 || h <= 0 || w > ctx->max_w || h > ctx->max_h)
+        return fail(ctx, DVO_ERR_INVALID_ARG, "image %dx%d outside the ctx maximum %dx%d", w, h, ctx->max_w, ctx->max_h);
+    if (levels < 1 || levels > ctx->max_levels) return fail(ctx, DVO_ERR_INVALID_ARG, "levels %d outside [1,%d]", levels, ctx->max_levels);
+    if ((w >> (levels - 1)) < 1 || (h >> (levels - 1)) < 1) return fail(ctx, DVO_ERR_INVALID_ARG, "%d levels is too many for a %dx%d image", levels, w, h);
+    SlotInfo& s = ctx->slots[slot];
+    if (s.w != w || s.h != h || s.levels != levels) {
+        // geometry of the slot changes: the zero pad row/column of the packed planes must be re-established
+        HIP_TRY(ctx, hipMemsetAsync(ctx->d_slots + (size_t)slot * ctx->slot_stride, 0, ctx->slot_stride, ctx->stream));
+    }
+    s.w = w; s.h = h; s.levels = levels; s.ready = false;
+    return DVO_OK;
+}
+
+}  // namespace
+
+// ==================================================================================================
+extern "C" {
+
+const char* dvo_last_error(const dvo_ctx* ctx) { return ctx ? ctx->err : g_create_error; }
+
+int dvo_create(int device, int max_w, int max_h, int max_levels, int n_slots, int max_pairs, dvo_ctx** out)
+{
+    if (!out) return fail(nullptr, DVO_ERR_INVALID_ARG, "dvo_create: out is null");
+    *out = nullptr;
+    if (max_w <= 0 || max_h <= 0 || max_levels < 1 || max_levels > DVO_MAX_LEVELS || n_slots < 2 || max_pairs < 1)
+        return fail(nullptr, DVO_ERR_INVALID_ARG, "dvo_create: bad sizes (max %dx%d, levels %d, slots %d, pairs %d)", max_w, max_h, max_levels, n_slots, max_pairs);
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0) return fail(nullptr, DVO_ERR_NO_DEVICE, "dvo_create: no HIP device (%s); there is no CPU fallback", hipGetErrorString(e));
+    if (device < 0 || device >= ndev) return fail(nullptr, DVO_ERR_INVALID_ARG, "dvo_create: device %d outside [0,%d)", device, ndev);
+    dvo_ctx* ctx = new (std::nothrow) dvo_ctx();
+    if (!ctx) return fail(nullptr, DVO_ERR_OUT_OF_MEMORY, "dvo_create: host allocation failed");
+#define CREATE_TRY(expr)                                                                           \
+    do {                                                                                           \
+        hipError_t _e = (expr);                                                                    \
+        if (_e != hipSuccess) {                                                                    \
+            int rc = fail(nullptr, (_e == hipErrorOutOfMemory) ? DVO_ERR_OUT_OF_MEMORY : DVO_ERR_HIP, \
+                          "dvo_create: %s failed: %s", #expr, hipGetErrorString(_e));              \
+            dvo_destroy(ctx);                                                                      \
+            return rc;                                                                             \
+        }                                                                                          \
+    } while (0)
+    ctx->device = device;
+    ctx->max_w = max_w; ctx->max_h = max_h; ctx->max_levels = max_levels; ctx->n_slots = n_slots; ctx->max_pairs = max_pairs;
+    CREATE_TRY(hipSetDevice(device));
+    CREATE_TRY(hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking));
+    ctx->stream = ctx->own_stream;
+    DvoLevelGeom g[DVO_MAX_LEVELS];
+    int lv = max_levels;
+    while (lv > 1 && ((max_w >> (lv - 1)) < 1 || (max_h >> (lv - 1)) < 1)) --lv;
+    level_geometry(max_w, max_h, lv, g, &ctx->slot_stride);
+    ctx->slot_stride = align_up(ctx->slot_stride, 4096);
+    ctx->slots.resize(n_slots);
+    CREATE_TRY(hipMalloc((void**)&ctx->d_slots, ctx->slot_stride * (size_t)n_slots));
+    CREATE_TRY(hipMemsetAsync(ctx->d_slots, 0, ctx->slot_stride * (size_t)n_slots, ctx->stream));
+    const size_t np = (size_t)max_pairs;
+    CREATE_TRY(hipMalloc((void**)&ctx->d_prev, np * sizeof(int)));
+    CREATE_TRY(hipMalloc((void**)&ctx->d_cur, np * sizeof(int)));
+    CREATE_TRY(hipMalloc((void**)&ctx->d_T, np * 12 * sizeof(float)));
+    CREATE_TRY(hipMalloc((void**)&ctx->d_Tinit, np * 12 * sizeof(float)));
+    CREATE_TRY(hipMalloc((void**)&ctx->d_wparam, np * sizeof(double)));
+    CREATE_TRY(hipMalloc((void**)&ctx->d_active, np * sizeof(int)));
+    ctx->partials_doubles = np * (size_t)blocks_for(max_w * max_h) * DVO_STRIDE;
+    CREATE_TRY(hipMalloc((void**)&ctx->d_partials, ctx->partials_doubles * sizeof(double)));
+    CREATE_TRY(hipMalloc((void**)&ctx->d_out, np * DVO_STRIDE * sizeof(double)));
+    CREATE_TRY(hipMalloc((void**)&ctx->d_state, np * sizeof(DvoPairState)));
+    CREATE_TRY(hipMalloc((void**)&ctx->d_xi, np * 6 * sizeof(double)));
+    CREATE_TRY(hipMalloc((void**)&ctx->d_iters, np * sizeof(int)));
+    CREATE_TRY(hipMalloc((void**)&ctx->d_err, np * sizeof(double)));
+    CREATE_TRY(hipMalloc((void**)&ctx->d_stage_img, (size_t)max_w * max_h * 5 + 256));
+    CREATE_TRY(hipMalloc((void**)&ctx->d_dense, (size_t)max_w * max_h * (9 * sizeof(float) + 1) + 256));
+    CREATE_TRY(hipHostMalloc((void**)&ctx->hs.prev, np * sizeof(int)));
+    CREATE_TRY(hipHostMalloc((void**)&ctx->hs.cur, np * sizeof(int)));
+    CREATE_TRY(hipHostMalloc((void**)&ctx->hs.T, np * 12 * sizeof(float)));
+    CREATE_TRY(hipHostMalloc((void**)&ctx->hs.wparam, np * sizeof(double)));
+    CREATE_TRY(hipHostMalloc((void**)&ctx->hs.out, np * DVO_STRIDE * sizeof(double)));
+    CREATE_TRY(hipHostMalloc((void**)&ctx->hs.xi, np * 6 * sizeof(double)));
+    CREATE_TRY(hipHostMalloc((void**)&ctx->hs.iters, np * sizeof(int)));
+    CREATE_TRY(hipHostMalloc((void**)&ctx->hs.err, np * sizeof(double)));
+    CREATE_TRY(hipEventCreate(&ctx->tm_a));
+    CREATE_TRY(hipEventCreate(&ctx->tm_b));
+    CREATE_TRY(hipStreamSynchronize(ctx->stream));
+#undef CREATE_TRY
+    *out = ctx;
+    return DVO_OK;
+}
+
+void dvo_destroy(dvo_ctx* ctx)
+{
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->own_stream) (void)hipStreamSynchronize(ctx->own_stream);
+    drain_profile(ctx);
+    for (hipEvent_t e : ctx->ev_pool) (void)hipEventDestroy(e);
+    if (ctx->tm_a) (void)hipEventDestroy(ctx->tm_a);
+    if (ctx->tm_b) (void)hipEventDestroy(ctx->tm_b);
+    void* dev[] = {ctx->d_slots, ctx->d_prev, ctx->d_cur, ctx->d_T, ctx->d_Tinit, ctx->d_wparam, ctx->d_active, ctx->d_partials,
+                   ctx->d_out, ctx->d_state, ctx->d_xi, ctx->d_iters, ctx->d_err, ctx->d_stage_img, ctx->d_dense, ctx->d_trace};
+    for (void* p : dev) if (p) (void)hipFree(p);
+    void* host[] = {ctx->hs.prev, ctx->hs.cur, ctx->hs.T, ctx->hs.wparam, ctx->hs.out, ctx->hs.xi, ctx->hs.iters, ctx->hs.err};
+    for (void* p : host) if (p) (void)hipHostFree(p);
+    if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
+    delete ctx;
+}
+
+int dvo_set_stream(dvo_ctx* ctx, void* hip_stream)
+{
+    if (!ctx) return DVO_ERR_INVALID_ARG;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
+    return DVO_OK;
+}
+
+int dvo_synchronize(dvo_ctx* ctx)
+{
+    if (!ctx) return DVO_ERR_INVALID_ARG;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return DVO_OK;
+}
+
+int dvo_set_camera(dvo_ctx* ctx, float fx, float fy, float cx, float cy, float skew, double depth_scale)
+{
+    if (!ctx) return DVO_ERR_INVALID_ARG;
+    if (!(fx > 0.f) || !(fy > 0.f) || !(depth_scale >= 0.0) || !std::isfinite(cx) || !std::isfinite(cy) || !std::isfinite(skew))
+        return fail(ctx, DVO_ERR_INVALID_ARG, "dvo_set_camera: need fx, fy > 0 and depth_scale >= 0");
+    ctx->fx = fx; ctx->fy = fy; ctx->cx = cx; ctx->cy = cy; ctx->skew = skew; ctx->depth_scale = depth_scale;
+    ctx->have_camera = true;
+    return DVO_OK;
+}
+
+int dvo_get_level_intrinsics(const dvo_ctx* ctx, int level, float* k)
+{
+    if (!ctx || !k) return DVO_ERR_INVALID_ARG;
+    if (!ctx->have_camera) return fail(const_cast<dvo_ctx*>(ctx), DVO_ERR_BAD_STATE, "camera not set");
+    if (level < 0 || level >= 30) return fail(const_cast<dvo_ctx*>(ctx), DVO_ERR_INVALID_ARG, "level %d out of range", level);
+    DvoLevelCam c = level_camera(ctx, level);
+    const float m[12] = {c.fx, c.s, c.cx, 0.f, 0.f, c.fy, c.cy, 0.f, 0.f, 0.f, 1.f, 0.f};
+    memcpy(k, m, sizeof(m));
+    return DVO_OK;
+}
+
+int dvo_upload_frame(dvo_ctx* ctx, int slot, const uint8_t* gray, const uint16_t* depth, int w, int h, int levels)
+{
+    if (!ctx) return DVO_ERR_INVALID_ARG;
+    if (!gray || !depth) return fail(ctx, DVO_ERR_INVALID_ARG, "dvo_upload_frame: null image");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    int rc = prepare_slot(ctx, slot, w, h, levels);
+    if (rc) return rc;
+    DvoLevelGeom g[DVO_MAX_LEVELS];
+    level_geometry(w, h, levels, g, nullptr);
+    uint8_t* base = ctx->d_slots + (size_t)slot * ctx->slot_stride;
+    HIP_TRY(ctx, hipMemcpyAsync(base + g[0].off_gray, gray, (size_t)w * h, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(base + g[0].off_depth, depth, (size_t)w * h * 2, hipMemcpyHostToDevice, ctx->stream));
+    rc = build_pyramid_on_device(ctx, slot, w, h, levels);
+    if (rc) return rc;
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));     // host buffers are only valid for the call
+    ctx->slots[slot].ready = true;
+    return DVO_OK;
+}
+
+int dvo_upload_frame_device(dvo_ctx* ctx, int slot, const void* d_gray, const void* d_depth, int w, int h, int levels)
+{
+    if (!ctx) return DVO_ERR_INVALID_ARG;
+    if (!d_gray || !d_depth) return fail(ctx, DVO_ERR_INVALID_ARG, "dvo_upload_frame_device: null image");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    int rc = prepare_slot(ctx, slot, w, h, levels);
+    if (rc) return rc;
+    DvoLevelGeom g[DVO_MAX_LEVELS];
+    level_geometry(w, h, levels, g, nullptr);
+    uint8_t* base = ctx->d_slots + (size_t)slot * ctx->slot_stride;
+    HIP_TRY(ctx, hipMemcpyAsync(base + g[0].off_gray, d_gray, (size_t)w * h, hipMemcpyDeviceToDevice, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(base + g[0].off_depth, d_depth, (size_t)w * h * 2, hipMemcpyDeviceToDevice, ctx->stream));
+    rc = build_pyramid_on_device(ctx, slot, w, h, levels);
+    if (rc) return rc;
+    ctx->slots[slot].ready = true;
+    return DVO_OK;
+}
+
+int dvo_upload_frame_bgr(dvo_ctx* ctx, int slot, const uint8_t* bgr, const uint16_t* depth, int w, int h, int levels,
+                         double max_distance)
+{
+    if (!ctx) return DVO_ERR_INVALID_ARG;
+    if (!bgr || !depth) return fail(ctx, DVO_ERR_INVALID_ARG, "dvo_upload_frame_bgr: null image");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    int rc = prepare_slot(ctx, slot, w, h, levels);
+    if (rc) return rc;
+    DvoLevelGeom g[DVO_MAX_LEVELS];
+    level_geometry(w, h, levels, g, nullptr);
+    uint8_t* base = ctx->d_slots + (size_t)slot * ctx->slot_stride;
+    const size_t n = (size_t)w * h;
+    uint8_t* st_bgr = ctx->d_stage_img;
+    uint16_t* st_depth = reinterpret_cast<uint16_t*>(ctx->d_stage_img + align_up(n * 3, 256));
+    HIP_TRY(ctx, hipMemcpyAsync(st_bgr, bgr, n * 3, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(st_depth, depth, n * 2, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, dvo_launch_bgr_ingest(st_bgr, st_depth, w, h, base + g[0].off_gray,
+                                       reinterpret_cast<uint16_t*>(base + g[0].off_depth), ctx->depth_scale, max_distance, ctx->stream));
+    rc = build_pyramid_on_device(ctx, slot, w, h, levels);
+    if (rc) return rc;
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->slots[slot].ready = true;
+    return DVO_OK;
+}
+
+int dvo_slot_info(const dvo_ctx* ctx, int slot, int* w, int* h, int* levels)
+{
+    if (!ctx) return DVO_ERR_INVALID_ARG;
+    if (slot < 0 || slot >= ctx->n_slots) return fail(const_cast<dvo_ctx*>(ctx), DVO_ERR_INVALID_ARG, "slot %d out of range", slot);
+    const SlotInfo& s = ctx->slots[slot];
+    if (w) *w = s.ready ? s.w : 0;
+    if (h) *h = s.ready ? s.h : 0;
+    if (levels) *levels = s.ready ? s.levels : 0;
+    return DVO_OK;
+}
+
+int dvo_download_level(dvo_ctx* ctx, int slot, int level, uint8_t* gray, uint16_t* depth, int16_t* gx, int16_t* gy)
+{
+    if (!ctx) return DVO_ERR_INVALID_ARG;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    int rc = check_slot(ctx, slot, "dvo_download_level");
+    if (rc) return rc;
+    const SlotInfo& s = ctx->slots[slot];
+    if (level < 0 || level >= s.levels) return fail(ctx, DVO_ERR_INVALID_ARG, "level %d outside [0,%d)", level, s.levels);
+    DvoLevelGeom g[DVO_MAX_LEVELS];
+    level_geometry(s.w, s.h, s.levels, g, nullptr);
+    const uint8_t* base = ctx->d_slots + (size_t)slot * ctx->slot_stride;
+    const size_t n = (size_t)g[level].npix;
+    if (gray) HIP_TRY(ctx, hipMemcpyAsync(gray, base + g[level].off_gray, n, hipMemcpyDeviceToHost, ctx->stream));
+    if (depth) HIP_TRY(ctx, hipMemcpyAsync(depth, base + g[level].off_depth, n * 2, hipMemcpyDeviceToHost, ctx->stream));
+    if (gx || gy) {
+        int16_t* dgx = reinterpret_cast<int16_t*>(ctx->d_dense);
+        int16_t* dgy = dgx + n;
+        HIP_TRY(ctx, dvo_launch_unpack(reinterpret_cast<const uint32_t*>(base + g[level].off_packed), g[level].w, g[level].h,
+                                       g[level].pitch, dgx, dgy, ctx->stream));
+        if (gx) HIP_TRY(ctx, hipMemcpyAsync(gx, dgx, n * 2, hipMemcpyDeviceToHost, ctx->stream));
+        if (gy) HIP_TRY(ctx, hipMemcpyAsync(gy, dgy, n * 2, hipMemcpyDeviceToHost, ctx->stream));
+    }
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return DVO_OK;
+}
+
+static int stage_pairs(dvo_ctx* ctx, int n_pairs, const int* prev_slot, const int* cur_slot, const float* T,
+                       const double* wparam)
+{
+    memcpy(ctx->hs.prev, prev_slot, n_pairs * sizeof(int));
+    memcpy(ctx->hs.cur, cur_slot, n_pairs * sizeof(int));
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->d_prev, ctx->hs.prev, n_pairs * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->d_cur, ctx->hs.cur, n_pairs * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+    if (T) {
+        memcpy(ctx->hs.T, T, (size_t)n_pairs * 12 * sizeof(float));
+        HIP_TRY(ctx, hipMemcpyAsync(ctx->d_T, ctx->hs.T, (size_t)n_pairs * 12 * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+    }
+    if (wparam) {
+        memcpy(ctx->hs.wparam, wparam, n_pairs * sizeof(double));
+        HIP_TRY(ctx, hipMemcpyAsync(ctx->d_wparam, ctx->hs.wparam, n_pairs * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    }
+    return DVO_OK;
+}
+
+static int check_variant(dvo_ctx* ctx, int variant)
+{
+    if (variant != DVO_VARIANT_V1 && variant != DVO_VARIANT_V2)
+        return fail(ctx, DVO_ERR_INVALID_ARG, "variant %d not available (V1=0, V2=1)", variant);
+    return DVO_OK;
+}
+
+int dvo_normal_equations(dvo_ctx* ctx, int level, int n_pairs, const int* prev_slot, const int* cur_slot,
+                         const float* T, int variant, int weight_mode, const double* weight_param, double* out)
+{
+    if (!ctx) return DVO_ERR_INVALID_ARG;
+    if (!T || !out) return fail(ctx, DVO_ERR_INVALID_ARG, "dvo_normal_equations: null T/out");
+    if (level < 0) return fail(ctx, DVO_ERR_INVALID_ARG, "level %d < 0", level);
+    if (weight_mode < 0 || weight_mode > 2) return fail(ctx, DVO_ERR_INVALID_ARG, "weight_mode %d unknown", weight_mode);
+    if (weight_mode != 0 && !weight_param) return fail(ctx, DVO_ERR_INVALID_ARG, "weight_param required for weight_mode %d", weight_mode);
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    int rc = check_variant(ctx, variant);
+    if (rc) return rc;
+    int w, h;
+    rc = check_pairs(ctx, n_pairs, prev_slot, cur_slot, level, &w, &h);
+    if (rc) return rc;
+    rc = stage_pairs(ctx, n_pairs, prev_slot, cur_slot, T, weight_mode ? weight_param : nullptr);
+    if (rc) return rc;
+    DvoReduceParams p;
+    rc = fill_reduce_params(ctx, level, n_pairs, w, h, &p);
+    if (rc) return rc;
+    HIP_TRY(ctx, launch_reduce_profiled(ctx, p, level, variant, weight_mode, 0));
+    HIP_TRY(ctx, dvo_launch_sum_partials(ctx->d_partials, p.blocks_per_pair, n_pairs, ctx->d_out, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->hs.out, ctx->d_out, (size_t)n_pairs * DVO_STRIDE * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    memcpy(out, ctx->hs.out, (size_t)n_pairs * DVO_STRIDE * sizeof(double));
+    return DVO_OK;
+}
+
+int dvo_weighted_r2_sum(dvo_ctx* ctx, int level, int n_pairs, const int* prev_slot, const int* cur_slot,
+                        const float* T, int variant, const double* lambda, double* out)
+{
+    if (!ctx) return DVO_ERR_INVALID_ARG;
+    if (!T || !out || !lambda) return fail(ctx, DVO_ERR_INVALID_ARG, "dvo_weighted_r2_sum: null argument");
+    if (level < 0) return fail(ctx, DVO_ERR_INVALID_ARG, "level %d < 0", level);
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    int rc = check_variant(ctx, variant);
+    if (rc) return rc;
+    int w, h;
+    rc = check_pairs(ctx, n_pairs, prev_slot, cur_slot, level, &w, &h);
+    if (rc) return rc;
+    rc = stage_pairs(ctx, n_pairs, prev_slot, cur_slot, T, lambda);
+    if (rc) return rc;
+    DvoReduceParams p;
+    rc = fill_reduce_params(ctx, level, n_pairs, w, h, &p);
+    if (rc) return rc;
+    HIP_TRY(ctx, launch_reduce_profiled(ctx, p, level, variant, 1, 1));
+    HIP_TRY(ctx, dvo_launch_sum_partials(ctx->d_partials, p.blocks_per_pair, n_pairs, ctx->d_out, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->hs.out, ctx->d_out, (size_t)n_pairs * DVO_STRIDE * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    for (int i = 0; i < n_pairs; ++i) out[i] = ctx->hs.out[(size_t)i * DVO_STRIDE];
+    return DVO_OK;
+}
+
+int dvo_residuals_jacobian(dvo_ctx* ctx, int level, int prev_slot, int cur_slot, const float* T, int variant,
+                           float* r, float* J, uint8_t* valid, float* uv)
+{
+    if (!ctx) return DVO_ERR_INVALID_ARG;
+    if (!T) return fail(ctx, DVO_ERR_INVALID_ARG, "dvo_residuals_jacobian: null T");
+    if (level < 0) return fail(ctx, DVO_ERR_INVALID_ARG, "level %d < 0", level);
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    int rc = check_variant(ctx, variant);
+    if (rc) return rc;
+    int w, h;
+    rc = check_pairs(ctx, 1, &prev_slot, &cur_slot, level, &w, &h);
+    if (rc) return rc;
+    DvoLevelGeom g[DVO_MAX_LEVELS];
+    level_geometry(w, h, level + 1, g, nullptr);
+    const size_t n = (size_t)g[level].npix;
+    DvoDenseParams p;
+    p.slots = ctx->d_slots;
+    p.slot_stride = ctx->slot_stride;
+    p.g = g[level];
+    p.cam = level_camera(ctx, level);
+    p.depth_scale = ctx->depth_scale;
+    p.prev_slot = prev_slot;
+    p.cur_slot = cur_slot;
+    memcpy(p.T, T, sizeof(p.T));
+    p.r = ctx->d_dense;
+    p.J = ctx->d_dense + n;
+    p.uv = ctx->d_dense + 7 * n;
+    p.valid = reinterpret_cast<uint8_t*>(ctx->d_dense + 9 * n);
+    HIP_TRY(ctx, dvo_launch_dense(p, variant, ctx->stream));
+    if (r) HIP_TRY(ctx, hipMemcpyAsync(r, p.r, n * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+    if (J) HIP_TRY(ctx, hipMemcpyAsync(J, p.J, 6 * n * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+    if (uv) HIP_TRY(ctx, hipMemcpyAsync(uv, p.uv, 2 * n * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+    if (valid) HIP_TRY(ctx, hipMemcpyAsync(valid, p.valid, n, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return DVO_OK;
+}
+
+int dvo_solve_batch_enqueue(dvo_ctx* ctx, int n_pairs, const int* prev_slot, const int* cur_slot, int levels,
+                            int max_iterations, double tolerance, int max_increased_steps_allowed, int variant,
+                            int weight_mode, double weight_param, const float* T_init)
+{
+    if (!ctx) return DVO_ERR_INVALID_ARG;
+    if (levels < 1 || max_iterations < 0) return fail(ctx, DVO_ERR_INVALID_ARG, "levels %d / max_iterations %d invalid", levels, max_iterations);
+    if (weight_mode < 0 || weight_mode > 2) return fail(ctx, DVO_ERR_INVALID_ARG, "weight_mode %d unknown", weight_mode);
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    int rc = check_variant(ctx, variant);
+    if (rc) return rc;
+    int w, h;
+    rc = check_pairs(ctx, n_pairs, prev_slot, cur_slot, levels - 1, &w, &h);
+    if (rc) return rc;
+    rc = stage_pairs(ctx, n_pairs, prev_slot, cur_slot, nullptr, nullptr);
+    if (rc) return rc;
+    const float* d_init = nullptr;
+    if (T_init) {
+        memcpy(ctx->hs.T, T_init, (size_t)n_pairs * 12 * sizeof(float));
+        HIP_TRY(ctx, hipMemcpyAsync(ctx->d_Tinit, ctx->hs.T, (size_t)n_pairs * 12 * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+        d_init = ctx->d_Tinit;
+    }
+    const double lambda0 = 1.0 / 25.0;                      // TDistributionWeighter: initial_sigma = 5 (t_weighter.py:11-15)
+    HIP_TRY(ctx, dvo_launch_init_state(ctx->d_state, ctx->d_T, d_init, n_pairs, lambda0, ctx->stream));
+    for (int level = levels - 1; level >= 0; --level) {
+        DvoReduceParams p;
+        rc = fill_reduce_params(ctx, level, n_pairs, w, h, &p);
+        if (rc) return rc;
+        p.active = ctx->d_active;
+        DvoSolveParams sp;
+        sp.partials = ctx->d_partials;
+        sp.blocks_per_pair = p.blocks_per_pair;
+        sp.n_pairs = n_pairs;
+        sp.state = ctx->d_state;
+        sp.T = ctx->d_T;
+        sp.active = ctx->d_active;
+        sp.wparam = ctx->d_wparam;
+        sp.tolerance = tolerance;
+        sp.max_increased = max_increased_steps_allowed;
+        sp.weight_mode = weight_mode;
+        sp.weight_param = weight_param;
+        sp.trace = ctx->d_trace;
+        sp.trace_stride = DVO_STRIDE + 18;
+        sp.trace_cap = ctx->trace_cap;
+        HIP_TRY(ctx, dvo_launch_level_begin(ctx->d_state, ctx->d_active, ctx->d_wparam, n_pairs, weight_mode, lambda0, ctx->stream));
+        for (int it = 0; it < max_iterations; ++it) {
+            if (weight_mode == DVO_WEIGHT_STUDENT_T) {
+                // the two IRLS scale passes the reference's loop takes (weighter/t_weighter.py:24-32)
+                for (int pass = 1; pass <= 2; ++pass) {
+                    HIP_TRY(ctx, launch_reduce_profiled(ctx, p, level, variant, 1, 1));
+                    sp.phase = pass;
+                    HIP_TRY(ctx, dvo_launch_solve(sp, ctx->stream));
+                }
+            }
+            HIP_TRY(ctx, launch_reduce_profiled(ctx, p, level, variant, weight_mode, 0));
+            sp.phase = 0;
+            HIP_TRY(ctx, dvo_launch_solve(sp, ctx->stream));
+        }
+    }
+    HIP_TRY(ctx, dvo_launch_finish(ctx->d_state, n_pairs, ctx->d_xi, ctx->d_iters, ctx->d_err, ctx->stream));
+    return DVO_OK;
+}
+
+int dvo_solve_batch_fetch(dvo_ctx* ctx, int n_pairs, float* T_out, double* xi_out, int* iters_out, double* err_out)
+{
+    if (!ctx) return DVO_ERR_INVALID_ARG;
+    if (n_pairs <= 0 || n_pairs > ctx->max_pairs) return fail(ctx, DVO_ERR_INVALID_ARG, "n_pairs %d outside [1,%d]", n_pairs, ctx->max_pairs);
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (T_out) HIP_TRY(ctx, hipMemcpyAsync(ctx->hs.T, ctx->d_T, (size_t)n_pairs * 12 * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+    if (xi_out) HIP_TRY(ctx, hipMemcpyAsync(ctx->hs.xi, ctx->d_xi, (size_t)n_pairs * 6 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    if (iters_out) HIP_TRY(ctx, hipMemcpyAsync(ctx->hs.iters, ctx->d_iters, (size_t)n_pairs * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    if (err_out) HIP_TRY(ctx, hipMemcpyAsync(ctx->hs.err, ctx->d_err, (size_t)n_pairs * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (T_out) memcpy(T_out, ctx->hs.T, (size_t)n_pairs * 12 * sizeof(float));
+    if (xi_out) memcpy(xi_out, ctx->hs.xi, (size_t)n_pairs * 6 * sizeof(double));
+    if (iters_out) memcpy(iters_out, ctx->hs.iters, (size_t)n_pairs * sizeof(int));
+    if (err_out) memcpy(err_out, ctx->hs.err, (size_t)n_pairs * sizeof(double));
+    return DVO_OK;
+}
+
+int dvo_solve_batch(dvo_ctx* ctx, int n_pairs, const int* prev_slot, const int* cur_slot, int levels,
+                    int max_iterations, double tolerance, int max_increased_steps_allowed, int variant,
+                    int weight_mode, double weight_param, const float* T_init, float* T_out, double* xi_out,
+                    int* iters_out, double* err_out)
+{
+    int rc = dvo_solve_batch_enqueue(ctx, n_pairs, prev_slot, cur_slot, levels, max_iterations, tolerance,
+                                     max_increased_steps_allowed, variant, weight_mode, weight_param, T_init);
+    if (rc) return rc;
+    return dvo_solve_batch_fetch(ctx, n_pairs, T_out, xi_out, iters_out, err_out);
+}
+
+int dvo_trace_enable(dvo_ctx* ctx, int max_iterations_traced)
+{
+    if (!ctx) return DVO_ERR_INVALID_ARG;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->d_trace) { (void)hipFree(ctx->d_trace); ctx->d_trace = nullptr; ctx->trace_cap = 0; }
+    if (max_iterations_traced <= 0) return DVO_OK;
+    const size_t n = (size_t)ctx->max_pairs * max_iterations_traced * (DVO_STRIDE + 18);
+    HIP_TRY(ctx, hipMalloc((void**)&ctx->d_trace, n * sizeof(double)));
+    HIP_TRY(ctx, hipMemsetAsync(ctx->d_trace, 0, n * sizeof(double), ctx->stream));
+    ctx->trace_cap = max_iterations_traced;
+    return DVO_OK;
+}
+
+int dvo_trace_read(dvo_ctx* ctx, int n_pairs, double* out)
+{
+    if (!ctx || !out) return DVO_ERR_INVALID_ARG;
+    if (!ctx->d_trace) return fail(ctx, DVO_ERR_BAD_STATE, "trace not enabled");
+    if (n_pairs <= 0 || n_pairs > ctx->max_pairs) return fail(ctx, DVO_ERR_INVALID_ARG, "n_pairs out of range");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const size_t n = (size_t)n_pairs * ctx->trace_cap * (DVO_STRIDE + 18);
+    HIP_TRY(ctx, hipMemcpyAsync(out, ctx->d_trace, n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return DVO_OK;
+}
+
+int dvo_profile_enable(dvo_ctx* ctx, int on)
+{
+    if (!ctx) return DVO_ERR_INVALID_ARG;
+    ctx->profiling = on != 0;
+    return DVO_OK;
+}
+
+int dvo_profile_read(dvo_ctx* ctx, int64_t* launches, double* ms, int reset)
+{
+    if (!ctx) return DVO_ERR_INVALID_ARG;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    drain_profile(ctx);
+    for (int i = 0; i < DVO_MAX_LEVELS; ++i) {
+        if (launches) launches[i] = ctx->prof_launches[i];
+        if (ms) ms[i] = ctx->prof_ms[i];
+        if (reset) { ctx->prof_launches[i] = 0; ctx->prof_ms[i] = 0.0; }
+    }
+    return DVO_OK;
+}
+
+int dvo_timer_start(dvo_ctx* ctx)
+{
+    if (!ctx) return DVO_ERR_INVALID_ARG;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipEventRecord(ctx->tm_a, ctx->stream));
+    return DVO_OK;
+}
+
+int dvo_timer_stop(dvo_ctx* ctx, float* ms)
+{
+    if (!ctx || !ms) return DVO_ERR_INVALID_ARG;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipEventRecord(ctx->tm_b, ctx->stream));
+    HIP_TRY(ctx, hipEventSynchronize(ctx->tm_b));
+    HIP_TRY(ctx, hipEventElapsedTime(ms, ctx->tm_a, ctx->tm_b));
+    return DVO_OK;
+}
+
+}  // extern "C"

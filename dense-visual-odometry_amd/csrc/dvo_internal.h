@@ -1,0 +1,103 @@
+// Internal structures shared by the C-ABI host code (dvo_abi.hip) and the kernels (dvo_kernels.hip).
+// gfx950 only; not part of the public boundary (see include/dvo_hip.h).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+
+#define DVO_BLOCK 256          // 4 wave64 per workgroup
+#define DVO_PX_PER_THREAD 4    // horizontally adjacent pixels per lane (ushort4 / uchar4 loads)
+#define DVO_PX_PER_BLOCK (DVO_BLOCK * DVO_PX_PER_THREAD)
+#define DVO_NACC 30            // 21 H + 6 J^T W r + sum w r^2 + N + sum r^2
+#define DVO_STRIDE 32          // doubles per normal-equation record (== DVO_NE_STRIDE)
+
+// One pyramid level of a frame slot: byte offsets inside the slot, image size, packed-plane pitch (pixels).
+struct DvoLevelGeom {
+    int w, h, pitch, npix;
+    size_t off_gray, off_depth, off_packed;
+};
+
+// Level intrinsics K_L (RGBDCameraModel.at, camera_model.py:62-79) and the entries of inv(K_L)
+// (camera_model.py:219) spelled out as in oracle/dvo_oracle.py:inverse_intrinsics.
+struct DvoLevelCam {
+    float fx, fy, cx, cy, s;
+    float ia, ib, ic, id, ie;   // inv(K) = [[ia ib ic],[0 id ie],[0 0 1]]
+};
+
+struct DvoReduceParams {
+    const uint8_t* slots;       // base of all frame slots
+    size_t slot_stride;
+    DvoLevelGeom g;
+    DvoLevelCam cam;
+    double depth_scale;
+    const int* prev_slot;       // [n_pairs]
+    const int* cur_slot;        // [n_pairs]
+    const float* T;             // [n_pairs][12] row-major [R|t]
+    const double* wparam;       // [n_pairs] lambda (student-t) or k (huber); may be null for WEIGHT_NONE
+    const int* active;          // [n_pairs] device-mode: 0 => pair skipped at this level; null => all active
+    double* partials;           // [n_pairs][blocks_per_pair][DVO_STRIDE]
+    int blocks_per_pair;
+    int n_pairs;
+};
+
+struct DvoDenseParams {
+    const uint8_t* slots;
+    size_t slot_stride;
+    DvoLevelGeom g;
+    DvoLevelCam cam;
+    double depth_scale;
+    int prev_slot, cur_slot;
+    float T[12];
+    float* r;          // [npix] or null
+    float* J;          // [npix][6] or null
+    uint8_t* valid;    // [npix] or null
+    float* uv;         // [npix][2] or null
+};
+
+// Per-pair Gauss-Newton state kept on the device by the fused solve (dvo_solve_batch).
+struct DvoPairState {
+    double q[4];        // estimate rotation, quaternion wxyz
+    double t[3];        // estimate translation
+    double err_prev;    // last accepted error (base_robust_dvo.py:158)
+    double err_last;    // error of the last evaluated iteration
+    double lambda;      // student-t: current lambda; huber: previous sigma (<=0: none yet)
+    int increased;      // err_increased_count (:159)
+    int active;         // 1 while this level is still iterating for this pair
+    int iters;          // total GN iterations evaluated
+    int pad;
+};
+
+struct DvoSolveParams {
+    const double* partials;     // [n_pairs][blocks_per_pair][DVO_STRIDE]
+    int blocks_per_pair;
+    int n_pairs;
+    DvoPairState* state;        // [n_pairs]
+    float* T;                   // [n_pairs][12] updated in place
+    int* active;                // [n_pairs]
+    double* wparam;             // [n_pairs] next-iteration weight parameter (written for student-t / huber)
+    double tolerance;
+    int max_increased;
+    int weight_mode;
+    double weight_param;        // huber: k multiplier
+    int phase;                  // 0: normal-equation iteration; 1/2: student-t scale passes
+    double* trace;              // optional [n_pairs][max_trace][DVO_STRIDE+8] per-iteration records, or null
+    int trace_stride, trace_cap;
+};
+
+// launch wrappers implemented in dvo_kernels.hip -------------------------------------------------
+hipError_t dvo_launch_median_down_u8(const uint8_t* src, int sw, int sh, uint8_t* dst, hipStream_t s);
+hipError_t dvo_launch_median_down_u16(const uint16_t* src, int sw, int sh, uint16_t* dst, hipStream_t s);
+hipError_t dvo_launch_sobel_pack(const uint8_t* gray, int w, int h, uint32_t* packed, int pitch, hipStream_t s);
+hipError_t dvo_launch_bgr_ingest(const uint8_t* bgr, const uint16_t* depth_in, int w, int h, uint8_t* gray,
+                                 uint16_t* depth_out, double depth_scale, double max_distance, hipStream_t s);
+hipError_t dvo_launch_unpack(const uint32_t* packed, int w, int h, int pitch, int16_t* gx, int16_t* gy, hipStream_t s);
+hipError_t dvo_launch_reduce(const DvoReduceParams& p, int variant, int weight_mode, int scale_pass, hipStream_t s);
+hipError_t dvo_launch_sum_partials(const double* partials, int blocks_per_pair, int n_pairs, double* out, hipStream_t s);
+hipError_t dvo_launch_dense(const DvoDenseParams& p, int variant, hipStream_t s);
+hipError_t dvo_launch_init_state(DvoPairState* st, float* T, const float* T_init, int n_pairs, double lambda0, hipStream_t s);
+hipError_t dvo_launch_level_begin(DvoPairState* st, int* active, double* wparam, int n_pairs, int weight_mode,
+                                  double lambda0, hipStream_t s);
+hipError_t dvo_launch_solve(const DvoSolveParams& p, hipStream_t s);
+hipError_t dvo_launch_finish(const DvoPairState* st, int n_pairs, double* xi_out, int* iters_out, double* err_out,
+                             hipStream_t s);

@@ -1,0 +1,772 @@
+// HIP kernels (gfx950 / CDNA4, wave64) of the dense RGB-D direct-alignment core.
+//
+// Built with -ffp-contract=off: the coordinate path (back-projection, SE(3) transform, projection) must
+// round exactly like oracle/dvo_oracle.py (IEEE float32, one rounding per operation, no FMA) so that the
+// in-bounds decision of every pixel is bit-identical; everywhere an FMA is wanted it is written fmaf().
+//
+// Kernels
+//   k_median_down<T>   K1  3x3 median (replicated border) + keep even rows/cols   (utils/image_pyramid.py:19-21)
+//   k_sobel_pack       K2  Sobel 3x3 BORDER_REFLECT, packed with the intensity     (utils/jacobian.py:47-73)
+//   k_bgr_ingest       K0  BGR->gray fixed point + depth clamp                     (core/base_dense_visual_odometry.py:58-59)
+//   k_reduce<...>      K3  residual + Jacobian + weight + 30-term reduction        (cpu_robust...:134-200 + base_robust_dvo.py:168-188)
+//                          (scale_pass form = K3s, weighter/t_weighter.py:36-47)
+//   k_sum_partials     K4  deterministic fixed-order sum of the per-workgroup partials
+//   k_dense<...>       K5  dense r / J / valid / uv writer (return contract of compute_residuals_and_jacobian)
+//   k_init_state, k_level_begin, k_solve, k_finish   device-side Gauss-Newton control (base_robust_dvo.py:152-232)
+//
+// References are relative to /root/reference/src/dense_visual_odometry/.
+#include "dvo_internal.h"
+#include <math.h>
+
+// ================================================================================================
+// K1: median 3x3 + decimate
+// ================================================================================================
+#define DVO_CSWAP(a, b) { unsigned _t = min(a, b); b = max(a, b); a = _t; }
+
+__device__ __forceinline__ unsigned median9(unsigned p0, unsigned p1, unsigned p2, unsigned p3, unsigned p4,
+                                            unsigned p5, unsigned p6, unsigned p7, unsigned p8)
+{
+    // 19-exchange median-of-9 network
+    DVO_CSWAP(p1, p2); DVO_CSWAP(p4, p5); DVO_CSWAP(p7, p8);
+    DVO_CSWAP(p0, p1); DVO_CSWAP(p3, p4); DVO_CSWAP(p6, p7);
+    DVO_CSWAP(p1, p2); DVO_CSWAP(p4, p5); DVO_CSWAP(p7, p8);
+    DVO_CSWAP(p0, p3); DVO_CSWAP(p5, p8); DVO_CSWAP(p4, p7);
+    DVO_CSWAP(p3, p6); DVO_CSWAP(p1, p4); DVO_CSWAP(p2, p5);
+    DVO_CSWAP(p4, p7); DVO_CSWAP(p4, p2); DVO_CSWAP(p6, p4);
+    DVO_CSWAP(p4, p2);
+    return p4;
+}
+
+template <typename T>
+__global__ __launch_bounds__(DVO_BLOCK) void k_median_down(const T* __restrict__ src, int sw, int sh,
+                                                           T* __restrict__ dst, int dw, int dh)
+{
+    int x = blockIdx.x * 64 + (threadIdx.x & 63);
+    int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= dw || y >= dh) return;
+    int cx = 2 * x, cy = 2 * y;
+    int xm = max(cx - 1, 0), xp = min(cx + 1, sw - 1);
+    int ym = max(cy - 1, 0), yp = min(cy + 1, sh - 1);
+    const T* r0 = src + (size_t)ym * sw;
+    const T* r1 = src + (size_t)cy * sw;
+    const T* r2 = src + (size_t)yp * sw;
+    unsigned m = median9(r0[xm], r0[cx], r0[xp], r1[xm], r1[cx], r1[xp], r2[xm], r2[cx], r2[xp]);
+    dst[(size_t)y * dw + x] = (T)m;
+}
+
+hipError_t dvo_launch_median_down_u8(const uint8_t* src, int sw, int sh, uint8_t* dst, hipStream_t s)
+{
+    int dw = (sw + 1) / 2, dh = (sh + 1) / 2;
+    dim3 grid((dw + 63) / 64, (dh + 3) / 4);
+    hipLaunchKernelGGL(k_median_down<uint8_t>, grid, dim3(DVO_BLOCK), 0, s, src, sw, sh, dst, dw, dh);
+    return hipGetLastError();
+}
+
+hipError_t dvo_launch_median_down_u16(const uint16_t* src, int sw, int sh, uint16_t* dst, hipStream_t s)
+{
+    int dw = (sw + 1) / 2, dh = (sh + 1) / 2;
+    dim3 grid((dw + 63) / 64, (dh + 3) / 4);
+    hipLaunchKernelGGL(k_median_down<uint16_t>, grid, dim3(DVO_BLOCK), 0, s, src, sw, sh, dst, dw, dh);
+    return hipGetLastError();
+}
+
+// ================================================================================================
+// K2: Sobel pack.  packed = I | (gx & 0xfff) << 8 | (gy & 0xfff) << 20 ; |gx|,|gy| <= 1020 < 2^11
+// ================================================================================================
+__global__ __launch_bounds__(DVO_BLOCK) void k_sobel_pack(const uint8_t* __restrict__ gray, int w, int h,
+                                                          uint32_t* __restrict__ packed, int pitch)
+{
+    int x = blockIdx.x * 64 + (threadIdx.x & 63);
+    int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= w || y >= h) return;
+    // BORDER_REFLECT (fedcba|abcdefgh|hgfedcb) with radius 1 == index clamp
+    int xm = max(x - 1, 0), xp = min(x + 1, w - 1);
+    int ym = max(y - 1, 0), yp = min(y + 1, h - 1);
+    const uint8_t* r0 = gray + (size_t)ym * w;
+    const uint8_t* r1 = gray + (size_t)y * w;
+    const uint8_t* r2 = gray + (size_t)yp * w;
+    int p00 = r0[xm], p01 = r0[x], p02 = r0[xp];
+    int p10 = r1[xm], p11 = r1[x], p12 = r1[xp];
+    int p20 = r2[xm], p21 = r2[x], p22 = r2[xp];
+    int gx = (p02 + 2 * p12 + p22) - (p00 + 2 * p10 + p20);
+    int gy = (p20 + 2 * p21 + p22) - (p00 + 2 * p01 + p02);
+    uint32_t v = (uint32_t)p11 | (((uint32_t)gx & 0xfffu) << 8) | (((uint32_t)gy & 0xfffu) << 20);
+    packed[(size_t)y * pitch + x] = v;
+}
+
+hipError_t dvo_launch_sobel_pack(const uint8_t* gray, int w, int h, uint32_t* packed, int pitch, hipStream_t s)
+{
+    dim3 grid((w + 63) / 64, (h + 3) / 4);
+    hipLaunchKernelGGL(k_sobel_pack, grid, dim3(DVO_BLOCK), 0, s, gray, w, h, packed, pitch);
+    return hipGetLastError();
+}
+
+__global__ __launch_bounds__(DVO_BLOCK) void k_unpack(const uint32_t* __restrict__ packed, int w, int h, int pitch,
+                                                      int16_t* __restrict__ gx, int16_t* __restrict__ gy)
+{
+    int x = blockIdx.x * 64 + (threadIdx.x & 63);
+    int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= w || y >= h) return;
+    uint32_t v = packed[(size_t)y * pitch + x];
+    if (gx) gx[(size_t)y * w + x] = (int16_t)(((int32_t)(v << 12)) >> 20);
+    if (gy) gy[(size_t)y * w + x] = (int16_t)(((int32_t)v) >> 20);
+}
+
+hipError_t dvo_launch_unpack(const uint32_t* packed, int w, int h, int pitch, int16_t* gx, int16_t* gy, hipStream_t s)
+{
+    dim3 grid((w + 63) / 64, (h + 3) / 4);
+    hipLaunchKernelGGL(k_unpack, grid, dim3(DVO_BLOCK), 0, s, packed, w, h, pitch, gx, gy);
+    return hipGetLastError();
+}
+
+// ================================================================================================
+// K0: colour ingest
+// ================================================================================================
+__global__ __launch_bounds__(DVO_BLOCK) void k_bgr_ingest(const uint8_t* __restrict__ bgr,
+                                                          const uint16_t* __restrict__ depth_in, int n,
+                                                          uint8_t* __restrict__ gray, uint16_t* __restrict__ depth_out,
+                                                          double depth_scale, double max_distance)
+{
+    int i = blockIdx.x * DVO_BLOCK + threadIdx.x;
+    if (i >= n) return;
+    int b = bgr[3 * (size_t)i], g = bgr[3 * (size_t)i + 1], r = bgr[3 * (size_t)i + 2];
+    gray[i] = (uint8_t)((b * 3735 + g * 19235 + r * 9798 + (1 << 14)) >> 15);
+    uint16_t d = depth_in[i];
+    // depth_image[(depth_image * depth_scale) > max_distance] = 0   (float64 product, as NumPy computes it)
+    depth_out[i] = ((double)d * depth_scale > max_distance) ? (uint16_t)0 : d;
+}
+
+hipError_t dvo_launch_bgr_ingest(const uint8_t* bgr, const uint16_t* depth_in, int w, int h, uint8_t* gray,
+                                 uint16_t* depth_out, double depth_scale, double max_distance, hipStream_t s)
+{
+    int n = w * h;
+    hipLaunchKernelGGL(k_bgr_ingest, dim3((n + DVO_BLOCK - 1) / DVO_BLOCK), dim3(DVO_BLOCK), 0, s, bgr, depth_in, n,
+                       gray, depth_out, depth_scale, max_distance);
+    return hipGetLastError();
+}
+
+// ================================================================================================
+// the per-pixel pipeline shared by K3 and K5
+// ================================================================================================
+struct PixelOut {
+    float r;
+    float J[6];
+    float uw, vw;
+    bool valid;
+};
+
+__device__ __forceinline__ float fast_rcp(float z)
+{
+    // v_rcp_f32 (1 ulp) + one Newton step; only used where the oracle tolerance is relative 1e-6, never
+    // on the coordinate path.
+    float r = __builtin_amdgcn_rcpf(z);
+    return fmaf(fmaf(-z, r, 1.0f), r, r);
+}
+
+__device__ __forceinline__ void unpack_tap(uint32_t p, float& I, float& gx, float& gy)
+{
+    I = (float)(p & 0xffu);
+    gx = (float)(((int32_t)(p << 12)) >> 20);
+    gy = (float)(((int32_t)p) >> 20);
+}
+
+struct __attribute__((packed, aligned(4))) u32x2_a4 { uint32_t a, b; };
+
+// VARIANT 0 (V1): gradient of I2 sampled at the warped point; 1 (V2): Sobel gradient of I1 at the pixel.
+template <int VARIANT, bool NEED_J>
+__device__ __forceinline__ void dvo_pixel(const DvoLevelGeom& g, const DvoLevelCam& cam, double depth_scale,
+                                          const float* __restrict__ T, const uint32_t* __restrict__ cur,
+                                          const uint32_t* __restrict__ prev_packed, int ux, int vy, unsigned d,
+                                          unsigned i1, PixelOut& o)
+{
+    // --- deproject (camera_model.py:195-221) -------------------------------------------------------
+    const float z = (float)((double)d * depth_scale);
+    const float u = (float)ux, v = (float)vy;
+    const float xn = ((cam.ia * u) + (cam.ib * v)) + cam.ic;
+    const float yn = (cam.id * v) + cam.ie;
+    const float x = xn * z;
+    const float y = yn * z;
+    // --- transform (cpu_robust...:173) and project (camera_model.py:247-252) -------------------------
+    const float xp = ((T[0] * x + T[1] * y) + T[2] * z) + T[3];
+    const float yp = ((T[4] * x + T[5] * y) + T[6] * z) + T[7];
+    const float zp = ((T[8] * x + T[9] * y) + T[10] * z) + T[11];
+    const float un = ((cam.fx * xp) + (cam.s * yp)) + (cam.cx * zp);
+    const float vn = (cam.fy * yp) + (cam.cy * zp);
+    const float uw = un / zp;      // IEEE division (hipcc default: correctly rounded)
+    const float vw = vn / zp;
+    o.uw = uw;
+    o.vw = vw;
+    // closed-boundary rule: valid <=> 0 <= x <= W-1 and 0 <= y <= H-1 ; NaN compares false
+    const bool ok = (uw >= 0.0f) && (uw <= (float)(g.w - 1)) && (vw >= 0.0f) && (vw <= (float)(g.h - 1));
+    o.valid = ok;
+    if (!ok) return;
+    // --- bilinear taps from the packed plane (cpu_robust...:202-254) ---------------------------------
+    const float x0f = floorf(uw), y0f = floorf(vw);
+    const int x0 = (int)x0f, y0 = (int)y0f;
+    const float ax = uw - x0f, ay = vw - y0f;          // exact
+    const float bx = (x0f + 1.0f) - uw, by = (y0f + 1.0f) - vw;
+    const float w00 = bx * by, w01 = bx * ay, w10 = ax * by, w11 = ax * ay;
+    const uint32_t* row0 = cur + (size_t)y0 * g.pitch + x0;
+    const u32x2_a4 t0 = *reinterpret_cast<const u32x2_a4*>(row0);             // (y0,x0) (y0,x1)
+    const u32x2_a4 t1 = *reinterpret_cast<const u32x2_a4*>(row0 + g.pitch);   // (y1,x0) (y1,x1)
+    float I00, I10, I01, I11, gx00, gx10, gx01, gx11, gy00, gy10, gy01, gy11;
+    unpack_tap(t0.a, I00, gx00, gy00);
+    unpack_tap(t0.b, I10, gx10, gy10);
+    unpack_tap(t1.a, I01, gx01, gy01);
+    unpack_tap(t1.b, I11, gx11, gy11);
+    const float i2 = fmaf(w11, I11, fmaf(w10, I10, fmaf(w01, I01, w00 * I00)));
+    o.r = i2 - (float)i1;                                                       // :191-194
+    if (!NEED_J) return;
+    float gxw, gyw;
+    if (VARIANT == 0) {
+        gxw = fmaf(w11, gx11, fmaf(w10, gx10, fmaf(w01, gx01, w00 * gx00)));    // :123-128
+        gyw = fmaf(w11, gy11, fmaf(w10, gy10, fmaf(w01, gy01, w00 * gy00)));
+    } else {
+        float Ip;
+        unpack_tap(prev_packed[(size_t)vy * g.pitch + ux], Ip, gxw, gyw);       // :69-75 (Sobel of I1 at the pixel)
+    }
+    // --- J_w at the UN-warped point (utils/jacobian.py:39-42, quirk Q2) ------------------------------
+    const float iz = fast_rcp(z);
+    const float a = x * iz, b = y * iz;
+    const float fxg = cam.fx * gxw, fyg = cam.fy * gyw;
+    // J = gx * Jw[0,:] + gy * Jw[1,:]   (_fill_jacobian, cpu_robust...:79-90)
+    o.J[0] = fxg * iz;
+    o.J[1] = fyg * iz;
+    o.J[2] = -(fxg * a + fyg * b) * iz;
+    o.J[3] = -(fxg * (a * b) + fyg * fmaf(b, b, 1.0f));
+    o.J[4] = fxg * fmaf(a, a, 1.0f) + fyg * (a * b);
+    o.J[5] = fyg * a - fxg * b;
+}
+
+// ================================================================================================
+// K3: fused residual/Jacobian/weight + normal-equation reduction
+// ================================================================================================
+__device__ __forceinline__ double wave_sum(double v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+template <int VARIANT, int WMODE, bool SCALE_PASS>
+__global__ __launch_bounds__(DVO_BLOCK) void k_reduce(const DvoReduceParams p)
+{
+    constexpr int NACC = SCALE_PASS ? 1 : DVO_NACC;
+    const int pair = blockIdx.x / p.blocks_per_pair;
+    const int blk = blockIdx.x - pair * p.blocks_per_pair;
+    if (p.active != nullptr && p.active[pair] == 0) return;        // block-uniform
+
+    const uint8_t* prev = p.slots + (size_t)p.prev_slot[pair] * p.slot_stride;
+    const uint8_t* curs = p.slots + (size_t)p.cur_slot[pair] * p.slot_stride;
+    const uint8_t* gray_prev = prev + p.g.off_gray;
+    const uint16_t* depth_prev = reinterpret_cast<const uint16_t*>(prev + p.g.off_depth);
+    const uint32_t* packed_prev = reinterpret_cast<const uint32_t*>(prev + p.g.off_packed);
+    const uint32_t* packed_cur = reinterpret_cast<const uint32_t*>(curs + p.g.off_packed);
+
+    float T[12];
+#pragma unroll
+    for (int i = 0; i < 12; ++i) T[i] = p.T[pair * 12 + i];
+    float wpar = 0.0f;
+    if (WMODE != 0) wpar = (float)p.wparam[pair];
+
+    float acc[NACC];
+#pragma unroll
+    for (int i = 0; i < NACC; ++i) acc[i] = 0.0f;
+
+    const int base = blk * DVO_PX_PER_BLOCK + threadIdx.x * DVO_PX_PER_THREAD;
+    if (base < p.g.npix) {
+        // planes are allocated with >= 16 bytes of slack, so the vector loads below never leave the slot
+        const ushort4 d4 = *reinterpret_cast<const ushort4*>(depth_prev + base);
+        const uchar4 i4 = *reinterpret_cast<const uchar4*>(gray_prev + base);
+        const unsigned dd[4] = {d4.x, d4.y, d4.z, d4.w};
+        const unsigned ii[4] = {i4.x, i4.y, i4.z, i4.w};
+        int vy = base / p.g.w;
+        int ux = base - vy * p.g.w;
+#pragma unroll
+        for (int j = 0; j < DVO_PX_PER_THREAD; ++j) {
+            if (base + j < p.g.npix && dd[j] != 0u) {                 // mask = depth != 0 (camera_model.py:195)
+                PixelOut o;
+                dvo_pixel<VARIANT, !SCALE_PASS>(p.g, p.cam, p.depth_scale, T, packed_cur, packed_prev, ux, vy,
+                                                dd[j], ii[j], o);
+                if (o.valid) {
+                    const float r = o.r;
+                    const float r2 = r * r;
+                    if (SCALE_PASS) {
+                        // r^2 * (dof+1)/(dof + r^2*lambda), dof = 5 (weighter/t_weighter.py:43-45)
+                        acc[0] += r2 * (6.0f * fast_rcp(fmaf(r2, wpar, 5.0f)));
+                    } else {
+                        float wt = 1.0f;
+                        if (WMODE == 1) wt = 6.0f * fast_rcp(fmaf(r2, wpar, 5.0f));          // t_weighter.py:34
+                        if (WMODE == 2) { const float ar = fabsf(r); wt = (ar <= wpar) ? 1.0f : wpar * fast_rcp(ar); }
+                        float wj[6];
+#pragma unroll
+                        for (int k = 0; k < 6; ++k) wj[k] = (WMODE == 0) ? o.J[k] : wt * o.J[k];
+                        int q = 0;
+#pragma unroll
+                        for (int a = 0; a < 6; ++a)
+#pragma unroll
+                            for (int b = a; b < 6; ++b) { acc[q] = fmaf(wj[a], o.J[b], acc[q]); ++q; }
+#pragma unroll
+                        for (int k = 0; k < 6; ++k) acc[21 + k] = fmaf(wj[k], r, acc[21 + k]);
+                        acc[27] = fmaf((WMODE == 0) ? r : wt * r, r, acc[27]);
+                        acc[28] += 1.0f;
+                        acc[29] += r2;
+                    }
+                }
+            }
+            if (++ux == p.g.w) { ux = 0; ++vy; }
+        }
+    }
+
+    // float32 only inside one lane (<= 4 pixels); everything across lanes / waves / workgroups is float64
+    __shared__ double lds[DVO_BLOCK / 64][DVO_STRIDE];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int i = 0; i < NACC; ++i) {
+        const double s = wave_sum((double)acc[i]);
+        if (lane == 0) lds[wave][i] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x < DVO_STRIDE) {
+        double s = 0.0;
+        if (threadIdx.x < NACC) s = (lds[0][threadIdx.x] + lds[1][threadIdx.x]) + (lds[2][threadIdx.x] + lds[3][threadIdx.x]);
+        p.partials[((size_t)pair * p.blocks_per_pair + blk) * DVO_STRIDE + threadIdx.x] = s;
+    }
+}
+
+template <int VARIANT>
+static hipError_t launch_reduce_v(const DvoReduceParams& p, int weight_mode, int scale_pass, hipStream_t s)
+{
+    dim3 grid((unsigned)(p.n_pairs * p.blocks_per_pair)), block(DVO_BLOCK);
+    if (scale_pass) {
+        hipLaunchKernelGGL((k_reduce<VARIANT, 1, true>), grid, block, 0, s, p);
+    } else if (weight_mode == 0) {
+        hipLaunchKernelGGL((k_reduce<VARIANT, 0, false>), grid, block, 0, s, p);
+    } else if (weight_mode == 1) {
+        hipLaunchKernelGGL((k_reduce<VARIANT, 1, false>), grid, block, 0, s, p);
+    } else {
+        hipLaunchKernelGGL((k_reduce<VARIANT, 2, false>), grid, block, 0, s, p);
+    }
+    return hipGetLastError();
+}
+
+hipError_t dvo_launch_reduce(const DvoReduceParams& p, int variant, int weight_mode, int scale_pass, hipStream_t s)
+{
+    if (variant == 0) return launch_reduce_v<0>(p, weight_mode, scale_pass, s);
+    return launch_reduce_v<1>(p, weight_mode, scale_pass, s);
+}
+
+// ================================================================================================
+// K4: fixed-order sum of the per-workgroup partials -> one record per pair
+// ================================================================================================
+__device__ __forceinline__ void sum_partials_block(const double* __restrict__ part, int nblk, double* rec /*LDS [32]*/)
+{
+    // 256 threads: column c = tid & 31, row group g = tid >> 5 (8 groups); fixed order => reproducible sums
+    __shared__ double tmp[8][DVO_STRIDE];
+    const int c = threadIdx.x & 31, g = threadIdx.x >> 5;
+    double s = 0.0;
+    for (int b = g; b < nblk; b += 8) s += part[(size_t)b * DVO_STRIDE + c];
+    tmp[g][c] = s;
+    __syncthreads();
+    if (threadIdx.x < DVO_STRIDE) {
+        double t = 0.0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) t += tmp[k][threadIdx.x];
+        rec[threadIdx.x] = t;
+    }
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(DVO_BLOCK) void k_sum_partials(const double* __restrict__ partials, int nblk,
+                                                            double* __restrict__ out)
+{
+    __shared__ double rec[DVO_STRIDE];
+    sum_partials_block(partials + (size_t)blockIdx.x * nblk * DVO_STRIDE, nblk, rec);
+    if (threadIdx.x < DVO_STRIDE) out[(size_t)blockIdx.x * DVO_STRIDE + threadIdx.x] = rec[threadIdx.x];
+}
+
+hipError_t dvo_launch_sum_partials(const double* partials, int blocks_per_pair, int n_pairs, double* out, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_sum_partials, dim3(n_pairs), dim3(DVO_BLOCK), 0, s, partials, blocks_per_pair, out);
+    return hipGetLastError();
+}
+
+// ================================================================================================
+// K5: dense writer
+// ================================================================================================
+template <int VARIANT>
+__global__ __launch_bounds__(DVO_BLOCK) void k_dense(const DvoDenseParams p)
+{
+    const int idx = blockIdx.x * DVO_BLOCK + threadIdx.x;
+    if (idx >= p.g.npix) return;
+    const uint8_t* prev = p.slots + (size_t)p.prev_slot * p.slot_stride;
+    const uint8_t* curs = p.slots + (size_t)p.cur_slot * p.slot_stride;
+    const uint8_t* gray_prev = prev + p.g.off_gray;
+    const uint16_t* depth_prev = reinterpret_cast<const uint16_t*>(prev + p.g.off_depth);
+    const uint32_t* packed_prev = reinterpret_cast<const uint32_t*>(prev + p.g.off_packed);
+    const uint32_t* packed_cur = reinterpret_cast<const uint32_t*>(curs + p.g.off_packed);
+    const int vy = idx / p.g.w, ux = idx - vy * p.g.w;
+    const unsigned d = depth_prev[idx];
+    PixelOut o;
+    o.valid = false;
+    o.r = 0.0f;
+    o.uw = o.vw = __builtin_nanf("");
+#pragma unroll
+    for (int k = 0; k < 6; ++k) o.J[k] = 0.0f;
+    if (d != 0u) {
+        float T[12];
+#pragma unroll
+        for (int i = 0; i < 12; ++i) T[i] = p.T[i];
+        dvo_pixel<VARIANT, true>(p.g, p.cam, p.depth_scale, T, packed_cur, packed_prev, ux, vy, d, gray_prev[idx], o);
+        if (!o.valid) {
+            o.r = 0.0f;
+#pragma unroll
+            for (int k = 0; k < 6; ++k) o.J[k] = 0.0f;
+        }
+    }
+    if (p.r) p.r[idx] = o.r;
+    if (p.valid) p.valid[idx] = o.valid ? 1 : 0;
+    if (p.J) {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) p.J[(size_t)idx * 6 + k] = o.J[k];
+    }
+    if (p.uv) { p.uv[(size_t)idx * 2] = o.uw; p.uv[(size_t)idx * 2 + 1] = o.vw; }
+}
+
+hipError_t dvo_launch_dense(const DvoDenseParams& p, int variant, hipStream_t s)
+{
+    dim3 grid((p.g.npix + DVO_BLOCK - 1) / DVO_BLOCK), block(DVO_BLOCK);
+    if (variant == 0) hipLaunchKernelGGL(k_dense<0>, grid, block, 0, s, p);
+    else hipLaunchKernelGGL(k_dense<1>, grid, block, 0, s, p);
+    return hipGetLastError();
+}
+
+// ================================================================================================
+// Device-side Gauss-Newton control (float64): 6x6 solve, SE(3) update, stop rules
+// ================================================================================================
+#define DVO_LIE_EPS 1e-6          // utils/lie_algebra/base_special_group.py:8
+#define DVO_FLT_MAX 3.4028234663852886e+38
+
+__device__ inline double wrap_angle_d(double a)
+{   // common.py:32-46 ; Python's % is a floored modulo
+    const double two_pi = 6.283185307179586;
+    double x = a + 3.141592653589793;
+    double m = x - floor(x / two_pi) * two_pi;
+    return m - 3.141592653589793;
+}
+
+__device__ inline void quat_to_R(const double* q, double* R)
+{   // So3.exp, special_orthogonal_group.py:158-189
+    const double w = q[0], x = q[1], y = q[2], z = q[3];
+    R[0] = 2 * (w * w + x * x) - 1; R[1] = 2 * (x * y - w * z);     R[2] = 2 * (x * z + w * y);
+    R[3] = 2 * (x * y + w * z);     R[4] = 2 * (w * w + y * y) - 1; R[5] = 2 * (y * z - w * x);
+    R[6] = 2 * (x * z - w * y);     R[7] = 2 * (y * z + w * x);     R[8] = 2 * (w * w + z * z) - 1;
+}
+
+__device__ inline void quat_log(const double* q, double* phi)
+{   // So3.log, special_orthogonal_group.py:191-209
+    const double n = sqrt(q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+    if (n < DVO_LIE_EPS) { phi[0] = phi[1] = phi[2] = 0.0; return; }
+    const double theta = wrap_angle_d(2.0 * atan2(n, q[0]) / n);
+    phi[0] = theta * q[1]; phi[1] = theta * q[2]; phi[2] = theta * q[3];
+}
+
+// Se3.from_se3 (special_euclidean_group.py:105-123): xi = (upsilon, omega) -> (q, t = V upsilon)
+__device__ inline void se3_from_xi(const double* xi, double* q, double* t)
+{
+    const double ox = xi[3], oy = xi[4], oz = xi[5];
+    double theta = sqrt(ox * ox + oy * oy + oz * oz);
+    if (theta < DVO_LIE_EPS) {
+        q[0] = 1; q[1] = q[2] = q[3] = 0;
+        t[0] = xi[0]; t[1] = xi[1]; t[2] = xi[2];
+        return;
+    }
+    const double ax = ox / theta, ay = oy / theta, az = oz / theta;
+    theta = wrap_angle_d(theta);                                   // So3.__init__ :46-50
+    double px = theta * ax, py = theta * ay, pz = theta * az;
+    const double th = sqrt(px * px + py * py + pz * pz);
+    if (th < DVO_LIE_EPS) {                                        // wrapped to ~0: So3.log would return 0
+        q[0] = 1; q[1] = q[2] = q[3] = 0;
+        t[0] = xi[0]; t[1] = xi[1]; t[2] = xi[2];
+        return;
+    }
+    const double s2 = sin(th * 0.5), c2 = cos(th * 0.5);
+    q[0] = c2; q[1] = s2 * px / th; q[2] = s2 * py / th; q[3] = s2 * pz / th;
+    // V = I + (1-cos)/th^2 [phi]x + (th - sin)/th^3 [phi]x^2
+    const double A = (1.0 - cos(th)) / (th * th), B = (th - sin(th)) / (th * th * th);
+    const double ux = xi[0], uy = xi[1], uz = xi[2];
+    const double c1x = py * uz - pz * uy, c1y = pz * ux - px * uz, c1z = px * uy - py * ux;          // phi x u
+    const double c2x = py * c1z - pz * c1y, c2y = pz * c1x - px * c1z, c2z = px * c1y - py * c1x;    // phi x (phi x u)
+    t[0] = ux + A * c1x + B * c2x;
+    t[1] = uy + A * c1y + B * c2y;
+    t[2] = uz + A * c1z + B * c2z;
+}
+
+// Se3.__mul__ (special_euclidean_group.py:91-96) with quat_mult (common.py:51-73): (qa,ta) * (qb,tb)
+__device__ inline void se3_mul(const double* qa, const double* ta, const double* qb, const double* tb, double* q, double* t)
+{
+    double R[9];
+    quat_to_R(qa, R);
+    const double w = qa[0] * qb[0] - (qa[1] * qb[1] + qa[2] * qb[2] + qa[3] * qb[3]);
+    const double x = qa[0] * qb[1] + qb[0] * qa[1] + (qa[2] * qb[3] - qa[3] * qb[2]);
+    const double y = qa[0] * qb[2] + qb[0] * qa[2] + (qa[3] * qb[1] - qa[1] * qb[3]);
+    const double z = qa[0] * qb[3] + qb[0] * qa[3] + (qa[1] * qb[2] - qa[2] * qb[1]);
+    const double t0 = ta[0] + R[0] * tb[0] + R[1] * tb[1] + R[2] * tb[2];
+    const double t1 = ta[1] + R[3] * tb[0] + R[4] * tb[1] + R[5] * tb[2];
+    const double t2 = ta[2] + R[6] * tb[0] + R[7] * tb[1] + R[8] * tb[2];
+    q[0] = w; q[1] = x; q[2] = y; q[3] = z;
+    t[0] = t0; t[1] = t1; t[2] = t2;
+}
+
+// Se3.exp (special_euclidean_group.py:35-52): rotation block is the identity when |log| < eps
+__device__ inline void se3_write_T(const double* q, const double* t, float* T)
+{
+    double phi[3], R[9];
+    quat_log(q, phi);
+    const double theta = sqrt(phi[0] * phi[0] + phi[1] * phi[1] + phi[2] * phi[2]);
+    if (theta < DVO_LIE_EPS) { R[0] = R[4] = R[8] = 1; R[1] = R[2] = R[3] = R[5] = R[6] = R[7] = 0; }
+    else quat_to_R(q, R);
+    T[0] = (float)R[0]; T[1] = (float)R[1]; T[2] = (float)R[2];  T[3] = (float)t[0];
+    T[4] = (float)R[3]; T[5] = (float)R[4]; T[6] = (float)R[5];  T[7] = (float)t[1];
+    T[8] = (float)R[6]; T[9] = (float)R[7]; T[10] = (float)R[8]; T[11] = (float)t[2];
+}
+
+// Se3.log (special_euclidean_group.py:54-77)
+__device__ inline void se3_log(const double* q, const double* t, double* xi)
+{
+    double phi[3];
+    quat_log(q, phi);
+    const double theta = sqrt(phi[0] * phi[0] + phi[1] * phi[1] + phi[2] * phi[2]);
+    if (theta < DVO_LIE_EPS) { xi[0] = t[0]; xi[1] = t[1]; xi[2] = t[2]; xi[3] = xi[4] = xi[5] = 0; return; }
+    const double ax = phi[0] / theta, ay = phi[1] / theta, az = phi[2] / theta;
+    const double t2 = theta * 0.5;
+    const double A = t2 * cos(t2) / sin(t2);
+    // V^-1 = A I + (1-A) a a^T - (theta/2) [a]x
+    const double adt = ax * t[0] + ay * t[1] + az * t[2];
+    const double cx = ay * t[2] - az * t[1], cy = az * t[0] - ax * t[2], cz = ax * t[1] - ay * t[0];
+    xi[0] = A * t[0] + (1 - A) * ax * adt - t2 * cx;
+    xi[1] = A * t[1] + (1 - A) * ay * adt - t2 * cy;
+    xi[2] = A * t[2] + (1 - A) * az * adt - t2 * cz;
+    xi[3] = phi[0]; xi[4] = phi[1]; xi[5] = phi[2];
+}
+
+// Solves H x = b for the symmetric positive semi-definite 6x6 H (upper triangle hu[21], row-major).
+// Fast path: Cholesky.  If a pivot is not safely positive (numerically rank deficient H) falls back to the
+// minimum-norm solution through a cyclic Jacobi eigen-decomposition, which is what LAPACK gelsy
+// (base_robust_dvo.py:196-198) returns for a rank-deficient system.
+__device__ inline void solve6(const double* hu, const double* b, double* x)
+{
+    double A[6][6];
+    {
+        int q = 0;
+        for (int i = 0; i < 6; ++i) for (int j = i; j < 6; ++j) { A[i][j] = hu[q]; A[j][i] = hu[q]; ++q; }
+    }
+    bool finite = true;
+    double dmax = 0.0;
+    for (int i = 0; i < 6; ++i) { dmax = fmax(dmax, fabs(A[i][i])); for (int j = 0; j < 6; ++j) finite = finite && isfinite(A[i][j]); }
+    for (int i = 0; i < 6; ++i) finite = finite && isfinite(b[i]);
+    if (!finite) { for (int i = 0; i < 6; ++i) x[i] = __builtin_nan(""); return; }
+    if (dmax == 0.0) { for (int i = 0; i < 6; ++i) x[i] = 0.0; return; }
+    double L[6][6];
+    bool ok = true;
+    for (int j = 0; j < 6 && ok; ++j) {
+        double d = A[j][j];
+        for (int k = 0; k < j; ++k) d -= L[j][k] * L[j][k];
+        if (!(d > 1e-13 * dmax)) { ok = false; break; }
+        const double lj = sqrt(d);
+        L[j][j] = lj;
+        for (int i = j + 1; i < 6; ++i) {
+            double s = A[i][j];
+            for (int k = 0; k < j; ++k) s -= L[i][k] * L[j][k];
+            L[i][j] = s / lj;
+        }
+    }
+    if (ok) {
+        double y[6];
+        for (int i = 0; i < 6; ++i) { double s = b[i]; for (int k = 0; k < i; ++k) s -= L[i][k] * y[k]; y[i] = s / L[i][i]; }
+        for (int i = 5; i >= 0; --i) { double s = y[i]; for (int k = i + 1; k < 6; ++k) s -= L[k][i] * x[k]; x[i] = s / L[i][i]; }
+        return;
+    }
+    // Jacobi eigen-decomposition A = V diag(e) V^T, pseudo-inverse with relative threshold eps_f64 * e_max
+    double V[6][6];
+    for (int i = 0; i < 6; ++i) for (int j = 0; j < 6; ++j) V[i][j] = (i == j) ? 1.0 : 0.0;
+    for (int sweep = 0; sweep < 30; ++sweep) {
+        double off = 0.0;
+        for (int i = 0; i < 6; ++i) for (int j = i + 1; j < 6; ++j) off += A[i][j] * A[i][j];
+        if (off <= 1e-60 * dmax * dmax || off == 0.0) break;
+        for (int p = 0; p < 5; ++p) for (int q = p + 1; q < 6; ++q) {
+            if (A[p][q] == 0.0) continue;
+            const double th = (A[q][q] - A[p][p]) / (2.0 * A[p][q]);
+            const double tt = (th >= 0 ? 1.0 : -1.0) / (fabs(th) + sqrt(th * th + 1.0));
+            const double c = 1.0 / sqrt(tt * tt + 1.0), s = tt * c;
+            for (int k = 0; k < 6; ++k) { const double akp = A[k][p], akq = A[k][q]; A[k][p] = c * akp - s * akq; A[k][q] = s * akp + c * akq; }
+            for (int k = 0; k < 6; ++k) { const double apk = A[p][k], aqk = A[q][k]; A[p][k] = c * apk - s * aqk; A[q][k] = s * apk + c * aqk; }
+            for (int k = 0; k < 6; ++k) { const double vkp = V[k][p], vkq = V[k][q]; V[k][p] = c * vkp - s * vkq; V[k][q] = s * vkp + c * vkq; }
+        }
+    }
+    double emax = 0.0;
+    for (int i = 0; i < 6; ++i) emax = fmax(emax, fabs(A[i][i]));
+    for (int i = 0; i < 6; ++i) x[i] = 0.0;
+    for (int k = 0; k < 6; ++k) {
+        const double e = A[k][k];
+        if (fabs(e) <= 2.220446049250313e-16 * emax) continue;
+        double vb = 0.0;
+        for (int i = 0; i < 6; ++i) vb += V[i][k] * b[i];
+        vb /= e;
+        for (int i = 0; i < 6; ++i) x[i] += V[i][k] * vb;
+    }
+}
+
+__global__ void k_init_state(DvoPairState* st, float* T, const float* T_init, int n_pairs, double lambda0)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_pairs) return;
+    DvoPairState s;
+    s.q[0] = 1; s.q[1] = s.q[2] = s.q[3] = 0;
+    s.t[0] = s.t[1] = s.t[2] = 0;
+    if (T_init != nullptr) {
+        // rotation matrix -> quaternion (So3._SE3_to_quat, special_orthogonal_group.py:86-127)
+        const float* M = T_init + (size_t)i * 12;
+        const double R[9] = {M[0], M[1], M[2], M[4], M[5], M[6], M[8], M[9], M[10]};
+        double tr = R[0] + R[4] + R[8];
+        if (tr > 0) {
+            double t = sqrt(1 + tr);
+            s.q[0] = 0.5 * t; t = 0.5 / t;
+            s.q[1] = (R[7] - R[5]) * t; s.q[2] = (R[2] - R[6]) * t; s.q[3] = (R[3] - R[1]) * t;
+        } else {
+            int a = 0;
+            if (R[4] > R[0]) a = 1;
+            if (R[8] > R[a * 4]) a = 2;
+            const int b = (a + 1) % 3, c = (b + 1) % 3;
+            double t = sqrt(R[a * 4] - R[b * 4] - R[c * 4] + 1);
+            s.q[1 + a] = 0.5 * t; t = 0.5 / t;
+            s.q[0] = (R[c * 3 + b] - R[b * 3 + c]) * t;
+            s.q[1 + b] = (R[b * 3 + a] + R[a * 3 + b]) * t;
+            s.q[1 + c] = (R[c * 3 + a] + R[a * 3 + c]) * t;
+        }
+        s.t[0] = M[3]; s.t[1] = M[7]; s.t[2] = M[11];
+    }
+    s.err_prev = DVO_FLT_MAX;
+    s.err_last = __builtin_nan("");
+    s.lambda = -1.0;
+    s.increased = 0;
+    s.active = 1;
+    s.iters = 0;
+    s.pad = 0;
+    st[i] = s;
+    se3_write_T(s.q, s.t, T + (size_t)i * 12);
+    (void)lambda0;
+}
+
+hipError_t dvo_launch_init_state(DvoPairState* st, float* T, const float* T_init, int n_pairs, double lambda0, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_init_state, dim3((n_pairs + 63) / 64), dim3(64), 0, s, st, T, T_init, n_pairs, lambda0);
+    return hipGetLastError();
+}
+
+// start of a pyramid level: err_prev = FLT_MAX, err_increased_count = 0 (base_robust_dvo.py:158-159)
+__global__ void k_level_begin(DvoPairState* st, int* active, double* wparam, int n_pairs, int weight_mode, double lambda0)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_pairs) return;
+    st[i].err_prev = DVO_FLT_MAX;
+    st[i].increased = 0;
+    st[i].active = 1;
+    active[i] = 1;
+    if (weight_mode == 1) wparam[i] = lambda0;                                     // t_weighter.py:23
+    if (weight_mode == 2) wparam[i] = (st[i].lambda > 0.0) ? st[i].lambda : DVO_FLT_MAX;   // no scale yet: w = 1
+}
+
+hipError_t dvo_launch_level_begin(DvoPairState* st, int* active, double* wparam, int n_pairs, int weight_mode,
+                                  double lambda0, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_level_begin, dim3((n_pairs + 63) / 64), dim3(64), 0, s, st, active, wparam, n_pairs,
+                       weight_mode, lambda0);
+    return hipGetLastError();
+}
+
+// One workgroup per pair: sum partials, then lane 0 runs the scalar control of one GN iteration.
+__global__ __launch_bounds__(DVO_BLOCK) void k_solve(const DvoSolveParams p)
+{
+    const int pair = blockIdx.x;
+    if (p.active[pair] == 0) return;
+    __shared__ double rec[DVO_STRIDE];
+    sum_partials_block(p.partials + (size_t)pair * p.blocks_per_pair * DVO_STRIDE, p.blocks_per_pair, rec);
+    if (threadIdx.x != 0) return;
+    DvoPairState& st = p.state[pair];
+
+    if (p.phase != 0) {
+        // Student-t scale pass k (weighter/t_weighter.py:24-32): lambda <- 1 / sum, stop when |d lambda| < 1e-3
+        const double last = p.wparam[pair];
+        if (st.pad == 0) {                       // pad: 1 once the IRLS loop has converged for this iteration
+            const double cur = 1.0 / rec[0];
+            if (fabs(cur - last) < 1e-3) st.pad = 1;
+            p.wparam[pair] = cur;
+        }
+        return;
+    }
+
+    const double n = rec[28];
+    double err = (n > 0.0) ? (double)(float)(rec[27] / n) : __builtin_nan("");      // np.mean(...) float32, :177/:184
+    double bneg[6], inc[6];
+    for (int i = 0; i < 6; ++i) bneg[i] = -rec[21 + i];                                // b = -J^T W r, :188
+    solve6(rec, bneg, inc);
+    st.iters += 1;
+    st.err_last = err;
+    if (p.trace != nullptr && st.iters <= p.trace_cap) {
+        double* tr = p.trace + ((size_t)pair * p.trace_cap + (st.iters - 1)) * p.trace_stride;
+        for (int i = 0; i < DVO_STRIDE; ++i) tr[i] = rec[i];
+        for (int i = 0; i < 6; ++i) tr[DVO_STRIDE + i] = inc[i];
+        for (int i = 0; i < 12; ++i) tr[DVO_STRIDE + 6 + i] = (double)p.T[(size_t)pair * 12 + i];
+    }
+    const double diff = err - st.err_prev;
+    bool stop = false;
+    if (fabs(diff) < p.tolerance) {                                                     // :207
+        stop = true;
+    } else {
+        if (diff < 0.0) {                                                               // :212-221
+            double qi[4], ti[3], qn[4], tn[3];
+            se3_from_xi(inc, qi, ti);
+            se3_mul(qi, ti, st.q, st.t, qn, tn);                                        // estimate = inc * estimate
+            for (int i = 0; i < 4; ++i) st.q[i] = qn[i];
+            for (int i = 0; i < 3; ++i) st.t[i] = tn[i];
+            st.err_prev = err;
+            st.increased = 0;
+            se3_write_T(st.q, st.t, p.T + (size_t)pair * 12);
+        } else {
+            st.increased += 1;                                                          // :222 (no rollback, quirk Q8)
+        }
+        if (st.increased > p.max_increased) stop = true;                                // :224
+    }
+    if (stop) { st.active = 0; p.active[pair] = 0; }
+    if (p.weight_mode == 1) { p.wparam[pair] = 1.0 / 25.0; st.pad = 0; }                // next iteration restarts IRLS
+    if (p.weight_mode == 2) {
+        const double sig = (n > 0.0) ? sqrt(rec[29] / n) : -1.0;
+        st.lambda = (sig > 0.0) ? p.weight_param * sig : -1.0;
+        p.wparam[pair] = (st.lambda > 0.0) ? st.lambda : DVO_FLT_MAX;
+    }
+}
+
+hipError_t dvo_launch_solve(const DvoSolveParams& p, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_solve, dim3(p.n_pairs), dim3(DVO_BLOCK), 0, s, p);
+    return hipGetLastError();
+}
+
+__global__ void k_finish(const DvoPairState* st, int n_pairs, double* xi_out, int* iters_out, double* err_out)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_pairs) return;
+    double xi[6];
+    se3_log(st[i].q, st[i].t, xi);
+    for (int k = 0; k < 6; ++k) xi_out[(size_t)i * 6 + k] = xi[k];
+    iters_out[i] = st[i].iters;
+    err_out[i] = st[i].err_prev;
+}
+
+hipError_t dvo_launch_finish(const DvoPairState* st, int n_pairs, double* xi_out, int* iters_out, double* err_out,
+                             hipStream_t s)
+{
+    hipLaunchKernelGGL(k_finish, dim3((n_pairs + 63) / 64), dim3(64), 0, s, st, n_pairs, xi_out, iters_out, err_out);
+    return hipGetLastError();
+}

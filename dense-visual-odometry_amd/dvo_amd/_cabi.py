@@ -1,0 +1,327 @@
+"""ctypes binding of libdvo_hip.so — the C ABI declared in include/dvo_hip.h.
+
+There is no fallback: if the shared library is missing the import of this module raises, and if no
+HIP device is present `HipContext(...)` raises `DVOHipError`.  Build the library with
+`python __graft_entry__.py` (or `make -C dense-visual-odometry_amd/csrc`).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from pathlib import Path
+from typing import Optional, Sequence
+
+import numpy as np
+
+NE_STRIDE = 32
+TRACE_STRIDE = 50
+MAX_LEVELS = 8
+
+VARIANT_V1, VARIANT_V2, VARIANT_V3 = 0, 1, 2
+WEIGHT_NONE, WEIGHT_STUDENT_T, WEIGHT_HUBER = 0, 1, 2
+
+_LIB_PATH = Path(__file__).resolve().parent / "libdvo_hip.so"
+
+# every symbol include/dvo_hip.h declares: name -> (restype, argtypes)
+_c_int_p = C.POINTER(C.c_int)
+_c_float_p = C.POINTER(C.c_float)
+_c_double_p = C.POINTER(C.c_double)
+_c_u8_p = C.POINTER(C.c_uint8)
+_c_u16_p = C.POINTER(C.c_uint16)
+_c_i16_p = C.POINTER(C.c_int16)
+_c_i64_p = C.POINTER(C.c_int64)
+_ctx = C.c_void_p
+
+SIGNATURES = {
+    "dvo_create": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(_ctx)]),
+    "dvo_destroy": (None, [_ctx]),
+    "dvo_last_error": (C.c_char_p, [_ctx]),
+    "dvo_set_stream": (C.c_int, [_ctx, C.c_void_p]),
+    "dvo_synchronize": (C.c_int, [_ctx]),
+    "dvo_set_camera": (C.c_int, [_ctx, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_double]),
+    "dvo_get_level_intrinsics": (C.c_int, [_ctx, C.c_int, _c_float_p]),
+    "dvo_upload_frame": (C.c_int, [_ctx, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int]),
+    "dvo_upload_frame_device": (C.c_int, [_ctx, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int]),
+    "dvo_upload_frame_bgr": (C.c_int, [_ctx, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_double]),
+    "dvo_download_level": (C.c_int, [_ctx, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "dvo_slot_info": (C.c_int, [_ctx, C.c_int, _c_int_p, _c_int_p, _c_int_p]),
+    "dvo_normal_equations": (C.c_int, [_ctx, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
+                                       C.c_void_p, C.c_void_p]),
+    "dvo_weighted_r2_sum": (C.c_int, [_ctx, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
+                                      C.c_void_p, C.c_void_p]),
+    "dvo_residuals_jacobian": (C.c_int, [_ctx, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p,
+                                         C.c_void_p, C.c_void_p, C.c_void_p]),
+    "dvo_solve_batch": (C.c_int, [_ctx, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_int,
+                                  C.c_int, C.c_int, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                  C.c_void_p]),
+    "dvo_solve_batch_enqueue": (C.c_int, [_ctx, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_double,
+                                          C.c_int, C.c_int, C.c_int, C.c_double, C.c_void_p]),
+    "dvo_solve_batch_fetch": (C.c_int, [_ctx, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "dvo_trace_enable": (C.c_int, [_ctx, C.c_int]),
+    "dvo_trace_read": (C.c_int, [_ctx, C.c_int, C.c_void_p]),
+    "dvo_profile_enable": (C.c_int, [_ctx, C.c_int]),
+    "dvo_profile_read": (C.c_int, [_ctx, _c_i64_p, _c_double_p, C.c_int]),
+    "dvo_timer_start": (C.c_int, [_ctx]),
+    "dvo_timer_stop": (C.c_int, [_ctx, _c_float_p]),
+}
+
+
+class DVOHipError(RuntimeError):
+    """A C-ABI call returned a negative dvo_status."""
+
+    def __init__(self, code: int, message: str):
+        super().__init__("libdvo_hip error {}: {}".format(code, message))
+        self.code = code
+
+
+def library_path() -> Path:
+    return _LIB_PATH
+
+
+def load_library() -> C.CDLL:
+    if not _LIB_PATH.exists():
+        raise ImportError(
+            "HIP extension {} is missing — build it with `python __graft_entry__.py` or "
+            "`make -C dense-visual-odometry_amd/csrc`; this package has no CPU fallback".format(_LIB_PATH))
+    lib = C.CDLL(str(_LIB_PATH))
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError if the .so does not export a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    return lib
+
+
+_lib: Optional[C.CDLL] = None
+
+
+def lib() -> C.CDLL:
+    global _lib
+    if _lib is None:
+        _lib = load_library()
+    return _lib
+
+
+def _ptr(a: Optional[np.ndarray]):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def _as(a, dtype, shape=None) -> np.ndarray:
+    out = np.ascontiguousarray(a, dtype=dtype)
+    if shape is not None:
+        out = out.reshape(shape)
+    return out
+
+
+class HipContext:
+    """Owns one `dvo_ctx` (one per GPU).  Thin, typed access to the C ABI with NumPy in/out."""
+
+    def __init__(self, device: int = 0, max_w: int = 640, max_h: int = 480, max_levels: int = 4, n_slots: int = 2,
+                 max_pairs: int = 1):
+        self._lib = lib()
+        self._h = _ctx()
+        rc = self._lib.dvo_create(device, max_w, max_h, max_levels, n_slots, max_pairs, C.byref(self._h))
+        if rc != 0:
+            msg = self._lib.dvo_last_error(None)
+            raise DVOHipError(rc, msg.decode() if msg else "dvo_create failed")
+        self.device, self.max_w, self.max_h = device, max_w, max_h
+        self.max_levels, self.n_slots, self.max_pairs = max_levels, n_slots, max_pairs
+
+    # -- plumbing ---------------------------------------------------------------------------------
+    def _check(self, rc: int):
+        if rc != 0:
+            msg = self._lib.dvo_last_error(self._h)
+            raise DVOHipError(rc, msg.decode() if msg else "")
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.dvo_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def set_stream(self, hip_stream: Optional[int]):
+        self._check(self._lib.dvo_set_stream(self._h, C.c_void_p(hip_stream) if hip_stream else None))
+
+    def synchronize(self):
+        self._check(self._lib.dvo_synchronize(self._h))
+
+    # -- camera -----------------------------------------------------------------------------------
+    def set_camera(self, fx, fy, cx, cy, skew, depth_scale):
+        self._check(self._lib.dvo_set_camera(self._h, float(fx), float(fy), float(cx), float(cy), float(skew),
+                                             float(depth_scale)))
+
+    def level_intrinsics(self, level: int) -> np.ndarray:
+        k = np.zeros((3, 4), dtype=np.float32)
+        self._check(self._lib.dvo_get_level_intrinsics(self._h, level, k.ctypes.data_as(_c_float_p)))
+        return k
+
+    # -- frames -----------------------------------------------------------------------------------
+    def upload_frame(self, slot: int, gray: np.ndarray, depth: np.ndarray, levels: int):
+        g = _as(gray, np.uint8)
+        d = _as(depth, np.uint16)
+        if g.ndim != 2 or g.shape != d.shape:
+            raise ValueError("gray {} and depth {} must be 2-D arrays of one shape".format(g.shape, d.shape))
+        h, w = g.shape
+        self._check(self._lib.dvo_upload_frame(self._h, slot, _ptr(g), _ptr(d), w, h, levels))
+
+    def upload_frame_device(self, slot: int, d_gray_ptr: int, d_depth_ptr: int, w: int, h: int, levels: int):
+        self._check(self._lib.dvo_upload_frame_device(self._h, slot, C.c_void_p(d_gray_ptr), C.c_void_p(d_depth_ptr),
+                                                      w, h, levels))
+
+    def upload_frame_bgr(self, slot: int, bgr: np.ndarray, depth: np.ndarray, levels: int, max_distance: float):
+        c = _as(bgr, np.uint8)
+        d = _as(depth, np.uint16)
+        if c.ndim != 3 or c.shape[2] != 3 or c.shape[:2] != d.shape:
+            raise ValueError("bgr {} must be HxWx3 matching depth {}".format(c.shape, d.shape))
+        h, w = d.shape
+        self._check(self._lib.dvo_upload_frame_bgr(self._h, slot, _ptr(c), _ptr(d), w, h, levels, float(max_distance)))
+
+    def slot_info(self, slot: int):
+        w, h, lv = C.c_int(), C.c_int(), C.c_int()
+        self._check(self._lib.dvo_slot_info(self._h, slot, C.byref(w), C.byref(h), C.byref(lv)))
+        return w.value, h.value, lv.value
+
+    def download_level(self, slot: int, level: int, want=("gray", "depth", "gx", "gy")):
+        w, h, lv = self.slot_info(slot)
+        if lv == 0:
+            raise DVOHipError(-5, "slot {} holds no frame".format(slot))
+        for _ in range(level):
+            w, h = (w + 1) // 2, (h + 1) // 2
+        out = {}
+        if "gray" in want:
+            out["gray"] = np.empty((h, w), dtype=np.uint8)
+        if "depth" in want:
+            out["depth"] = np.empty((h, w), dtype=np.uint16)
+        if "gx" in want:
+            out["gx"] = np.empty((h, w), dtype=np.int16)
+        if "gy" in want:
+            out["gy"] = np.empty((h, w), dtype=np.int16)
+        self._check(self._lib.dvo_download_level(self._h, slot, level, _ptr(out.get("gray")), _ptr(out.get("depth")),
+                                                 _ptr(out.get("gx")), _ptr(out.get("gy"))))
+        return out
+
+    # -- hot path ---------------------------------------------------------------------------------
+    def normal_equations(self, level: int, prev_slots: Sequence[int], cur_slots: Sequence[int], T: np.ndarray,
+                         variant: int = VARIANT_V1, weight_mode: int = WEIGHT_NONE,
+                         weight_param: Optional[np.ndarray] = None) -> np.ndarray:
+        """-> (n_pairs, 32) float64 records (layout in include/dvo_hip.h)."""
+        ps = _as(prev_slots, np.int32)
+        cs = _as(cur_slots, np.int32)
+        n = ps.shape[0]
+        Tm = _as(T, np.float32).reshape(n, -1)
+        if Tm.shape[1] == 16:
+            Tm = np.ascontiguousarray(Tm[:, :12])
+        if Tm.shape[1] != 12:
+            raise ValueError("T must be n x 3x4 (or 4x4) row-major")
+        wp = None if weight_param is None else _as(weight_param, np.float64, (n,))
+        out = np.empty((n, NE_STRIDE), dtype=np.float64)
+        self._check(self._lib.dvo_normal_equations(self._h, level, n, _ptr(ps), _ptr(cs), _ptr(Tm), variant,
+                                                   weight_mode, _ptr(wp), _ptr(out)))
+        return out
+
+    def weighted_r2_sum(self, level: int, prev_slots, cur_slots, T, lam, variant: int = VARIANT_V1) -> np.ndarray:
+        ps = _as(prev_slots, np.int32)
+        cs = _as(cur_slots, np.int32)
+        n = ps.shape[0]
+        Tm = _as(T, np.float32).reshape(n, -1)
+        if Tm.shape[1] == 16:
+            Tm = np.ascontiguousarray(Tm[:, :12])
+        lm = _as(lam, np.float64, (n,))
+        out = np.empty(n, dtype=np.float64)
+        self._check(self._lib.dvo_weighted_r2_sum(self._h, level, n, _ptr(ps), _ptr(cs), _ptr(Tm), variant, _ptr(lm),
+                                                  _ptr(out)))
+        return out
+
+    def residuals_jacobian(self, level: int, prev_slot: int, cur_slot: int, T: np.ndarray, variant: int = VARIANT_V1,
+                           want_uv: bool = True):
+        """Dense (h*w) outputs: r, J (h*w,6), valid (bool), uv (h*w,2)."""
+        w, h, lv = self.slot_info(prev_slot)
+        for _ in range(level):
+            w, h = (w + 1) // 2, (h + 1) // 2
+        n = w * h
+        Tm = _as(T, np.float32).reshape(-1)[:12].copy()
+        r = np.empty(n, dtype=np.float32)
+        J = np.empty((n, 6), dtype=np.float32)
+        valid = np.empty(n, dtype=np.uint8)
+        uv = np.empty((n, 2), dtype=np.float32) if want_uv else None
+        self._check(self._lib.dvo_residuals_jacobian(self._h, level, prev_slot, cur_slot, _ptr(Tm), variant, _ptr(r),
+                                                     _ptr(J), _ptr(valid), _ptr(uv)))
+        return r, J, valid.astype(bool), uv, (h, w)
+
+    def solve_batch(self, prev_slots, cur_slots, levels: int, max_iterations: int = 100, tolerance: float = 1e-6,
+                    max_increased_steps_allowed: int = 0, variant: int = VARIANT_V1, weight_mode: int = WEIGHT_NONE,
+                    weight_param: float = 0.0, T_init: Optional[np.ndarray] = None):
+        """Whole coarse-to-fine GN solve on the device. -> dict(T (n,3,4) f32, xi (n,6) f64, iters, err)."""
+        self.solve_batch_enqueue(prev_slots, cur_slots, levels, max_iterations, tolerance,
+                                 max_increased_steps_allowed, variant, weight_mode, weight_param, T_init)
+        return self.solve_batch_fetch(len(prev_slots))
+
+    def solve_batch_enqueue(self, prev_slots, cur_slots, levels, max_iterations=100, tolerance=1e-6,
+                            max_increased_steps_allowed=0, variant=VARIANT_V1, weight_mode=WEIGHT_NONE,
+                            weight_param=0.0, T_init=None):
+        ps = _as(prev_slots, np.int32)
+        cs = _as(cur_slots, np.int32)
+        n = ps.shape[0]
+        Ti = None
+        if T_init is not None:
+            Ti = _as(T_init, np.float32).reshape(n, -1)
+            if Ti.shape[1] == 16:
+                Ti = np.ascontiguousarray(Ti[:, :12])
+        self._check(self._lib.dvo_solve_batch_enqueue(self._h, n, _ptr(ps), _ptr(cs), levels, max_iterations,
+                                                      float(tolerance), max_increased_steps_allowed, variant,
+                                                      weight_mode, float(weight_param), _ptr(Ti)))
+
+    def solve_batch_fetch(self, n: int):
+        T = np.empty((n, 3, 4), dtype=np.float32)
+        xi = np.empty((n, 6), dtype=np.float64)
+        iters = np.empty(n, dtype=np.int32)
+        err = np.empty(n, dtype=np.float64)
+        self._check(self._lib.dvo_solve_batch_fetch(self._h, n, _ptr(T), _ptr(xi), _ptr(iters), _ptr(err)))
+        return dict(T=T, xi=xi, iters=iters, err=err)
+
+    def trace_enable(self, cap: int):
+        self._check(self._lib.dvo_trace_enable(self._h, cap))
+        self._trace_cap = cap
+
+    def trace_read(self, n: int) -> np.ndarray:
+        out = np.zeros((n, self._trace_cap, TRACE_STRIDE), dtype=np.float64)
+        self._check(self._lib.dvo_trace_read(self._h, n, _ptr(out)))
+        return out
+
+    # -- measurement ------------------------------------------------------------------------------
+    def profile_enable(self, on: bool):
+        self._check(self._lib.dvo_profile_enable(self._h, int(bool(on))))
+
+    def profile_read(self, reset: bool = True):
+        launches = np.zeros(MAX_LEVELS, dtype=np.int64)
+        ms = np.zeros(MAX_LEVELS, dtype=np.float64)
+        self._check(self._lib.dvo_profile_read(self._h, launches.ctypes.data_as(_c_i64_p),
+                                               ms.ctypes.data_as(_c_double_p), int(bool(reset))))
+        return launches, ms
+
+    def timer_start(self):
+        self._check(self._lib.dvo_timer_start(self._h))
+
+    def timer_stop(self) -> float:
+        ms = C.c_float()
+        self._check(self._lib.dvo_timer_stop(self._h, C.byref(ms)))
+        return float(ms.value)
+
+
+def unpack_record(rec: np.ndarray):
+    """(32,) record -> H (6,6), b (6,) [already negated: b = -J^T W r], sum_wr2, n, sum_r2."""
+    rec = np.asarray(rec, dtype=np.float64)
+    H = np.zeros((6, 6), dtype=np.float64)
+    iu = np.triu_indices(6)
+    H[iu] = rec[:21]
+    H = H + H.T - np.diag(np.diag(H))
+    return H, -rec[21:27], float(rec[27]), int(round(rec[28])), float(rec[29])

@@ -1,0 +1,339 @@
+"""`RobustDVOHIP` — third backend behind the reference's `BaseRobustDVO` boundary, running on MI355X.
+
+Mirrors, for this one path, the public surface of
+  core/base_dense_visual_odometry.py:21-91        (`step`, `current_pose`, first-frame handling, pose chaining)
+  core/robust_dense_visual_odometry/base_robust_dvo.py:25-236   (ctor kwargs, `levels`, `_step`, the four hooks)
+  core/robust_dense_visual_odometry/gpu_robust_dense_visual_odometry.py:14-122 (precedent: `height`, `width` kwargs)
+with every per-pixel computation done by the hand-written HIP kernels behind the C ABI (`_cabi.py`).
+
+Differences a maintainer should know about (all switchable or inert for the reference's defaults):
+  * the hot loop never materialises r / J: `_step` uses the added hook `compute_normal_equations`, the device
+    reduces H = J^T W J and J^T W r in float64 and the host solves one 6x6 system per GN iteration
+    (`solver="host"`, default) — or the whole loop runs on the device (`solver="device"`);
+  * `compute_residuals_and_jacobian` keeps the reference's return contract through the dense debug kernel;
+  * the previous frame's pyramid stays resident on the device instead of being rebuilt every step (quirk Q9);
+  * the sigma motion prior (base_robust_dvo.py:190-194) is not on this path: `sigma` must be None.
+"""
+from __future__ import annotations
+
+import logging
+from typing import Optional, Tuple
+
+import numpy as np
+import scipy.linalg
+
+from . import _cabi
+from .camera import RGBDCameraModel
+from .lie import Se3
+
+logger = logging.getLogger(__name__)
+
+
+class DVOError(Exception):
+    pass
+
+
+class ImagePyramidError(Exception):
+    pass
+
+
+_VARIANTS = {"v1": _cabi.VARIANT_V1, "v2": _cabi.VARIANT_V2}
+_WEIGHTS = {"none": _cabi.WEIGHT_NONE, "student_t_reference": _cabi.WEIGHT_STUDENT_T, "huber": _cabi.WEIGHT_HUBER}
+
+
+class DevicePyramid:
+    """View of one device-resident pyramid (`ImagePyramid.at(level)` surface, utils/image_pyramid.py:35-65);
+    levels are downloaded lazily — the hot path never needs them on the host."""
+
+    def __init__(self, ctx: "_cabi.HipContext", slot: int, levels: int, kind: str):
+        self._ctx, self._slot, self._levels, self._kind = ctx, slot, levels, kind
+        self._cache = {}
+
+    @property
+    def levels(self) -> int:
+        return self._levels
+
+    def at(self, level: int) -> np.ndarray:
+        if (level < 0) or level >= self._levels:
+            raise IndexError("'level' out of range [0, {}], got {} instead".format(self._levels - 1, level))
+        if level not in self._cache:
+            self._cache[level] = self._ctx.download_level(self._slot, level, want=(self._kind,))[self._kind]
+        return self._cache[level]
+
+
+class RobustDVOHIP:
+    """Kerl/Sturm/Cremers robust dense visual odometry, per-pixel work on the GPU."""
+
+    def __init__(self, camera_model: RGBDCameraModel, initial_pose: Se3, levels: int, use_weighter: bool = False,
+                 max_increased_steps_allowed: int = 0, sigma: float = None, tolerance: float = 1e-6,
+                 max_iterations: int = 100, approximate_image2_gradient: bool = False,
+                 height: int = 480, width: int = 640, device: int = 0, solver: str = "host",
+                 weighting: Optional[str] = None, huber_k: float = 1.345, max_distance: float = 5.0,
+                 mutate_depth: bool = True):
+        if sigma is not None:
+            raise NotImplementedError("the sigma motion prior (base_robust_dvo.py:190-194) is outside the HIP hot path")
+        if levels < 1:
+            raise ValueError("Expected 'levels' to be >= 1, got '{}' instead".format(levels))
+        if solver not in ("host", "device"):
+            raise ValueError("solver must be 'host' or 'device', got '{}'".format(solver))
+        self._camera_model = camera_model
+        self._initial_pose = initial_pose
+        self._current_pose = initial_pose.copy()
+        self._last_pose = None
+        self._last_estimated_transform = None
+        self._max_distance = max_distance
+        self._levels = levels
+        self._max_increased_steps_allowed = max_increased_steps_allowed
+        self._sigma = None
+        self._tolerance = tolerance
+        self._max_iter = max_iterations
+        self._approximate_image2_gradients = approximate_image2_gradient
+        self._variant = _cabi.VARIANT_V2 if approximate_image2_gradient else _cabi.VARIANT_V1
+        if weighting is None:
+            weighting = "student_t_reference" if use_weighter else "none"
+        if weighting not in _WEIGHTS:
+            raise ValueError("weighting must be one of {}, got '{}'".format(sorted(_WEIGHTS), weighting))
+        self._weighting = weighting
+        self._huber_k = huber_k
+        self._solver = solver
+        self._mutate_depth = mutate_depth
+
+        self._ctx = _cabi.HipContext(device=device, max_w=width, max_h=height, max_levels=levels, n_slots=2, max_pairs=1)
+        K = camera_model.intrinsics
+        self._ctx.set_camera(K[0, 0], K[1, 1], K[0, 2], K[1, 2], K[0, 1], camera_model.depth_scale)
+        self._prev_slot, self._cur_slot = 0, 1
+        self._have_prev = False
+        self._gray_image_prev = None        # kept as flags/handles for API parity; data lives on the device
+        self._depth_image_prev = None
+        self._curr_gray_image_pyr = None
+        self._prev_gray_image_pyr = None
+        self._curr_depth_image_pyr = None
+        self._prev_depth_image_pyr = None
+        self._huber_sigma = None
+        self.last_iterations = 0
+
+    # -- reference-facing properties ---------------------------------------------------------------------
+    @property
+    def levels(self) -> int:
+        return self._levels
+
+    @property
+    def current_pose(self) -> Se3:
+        return self._current_pose
+
+    @property
+    def context(self) -> "_cabi.HipContext":
+        return self._ctx
+
+    # -- frame driver (core/base_dense_visual_odometry.py:54-87) -------------------------------------------
+    def step(self, color_image: np.ndarray, depth_image: np.ndarray, init_guess: Se3 = None, **kwargs):
+        if init_guess is None:
+            init_guess = Se3.identity()
+        if color_image.ndim != 3 or color_image.shape[2] != 3:
+            raise ValueError("color_image must be HxWx3 (BGR), got {}".format(color_image.shape))
+        if self._mutate_depth:
+            # the reference zeroes far depth in the caller's array (quirk Q7); the device applies the same rule
+            depth_image[(depth_image * self._camera_model.depth_scale) > self._max_distance] = 0
+        target = self._cur_slot if self._have_prev else self._prev_slot
+        self._ctx.upload_frame_bgr(target, color_image, depth_image, self._levels, self._max_distance)
+        if not self._have_prev:
+            transform = Se3.identity()
+        else:
+            self._set_pyramid_views()
+            transform = self._gauss_newton(init_guess)
+        if transform is not None:
+            self._last_pose = self._current_pose.copy()
+            self._last_estimated_transform = transform.copy()
+            self._current_pose = self._current_pose * transform.inverse()     # :79
+            if self._have_prev:
+                self._prev_slot, self._cur_slot = self._cur_slot, self._prev_slot
+            self._have_prev = True
+            self._gray_image_prev = True
+            self._depth_image_prev = True
+        else:
+            logger.warning("DVO could not estimate transform, trying luck on next frame..")
+        return transform
+
+    def step_gray(self, gray_image: np.ndarray, depth_image: np.ndarray, init_guess: Se3 = None):
+        """`step` for callers that already hold the gray image (skips the colour conversion)."""
+        if init_guess is None:
+            init_guess = Se3.identity()
+        target = self._cur_slot if self._have_prev else self._prev_slot
+        self._ctx.upload_frame(target, gray_image, depth_image, self._levels)
+        if not self._have_prev:
+            transform = Se3.identity()
+        else:
+            self._set_pyramid_views()
+            transform = self._gauss_newton(init_guess)
+        self._last_pose = self._current_pose.copy()
+        self._last_estimated_transform = transform.copy()
+        self._current_pose = self._current_pose * transform.inverse()
+        if self._have_prev:
+            self._prev_slot, self._cur_slot = self._cur_slot, self._prev_slot
+        self._have_prev = True
+        self._gray_image_prev = True
+        self._depth_image_prev = True
+        return transform
+
+    # -- the four backend hooks (base_robust_dvo.py:91-135) ------------------------------------------------
+    def _set_pyramid_views(self):
+        self._prev_gray_image_pyr = DevicePyramid(self._ctx, self._prev_slot, self._levels, "gray")
+        self._prev_depth_image_pyr = DevicePyramid(self._ctx, self._prev_slot, self._levels, "depth")
+        self._curr_gray_image_pyr = DevicePyramid(self._ctx, self._cur_slot, self._levels, "gray")
+        self._curr_depth_image_pyr = DevicePyramid(self._ctx, self._cur_slot, self._levels, "depth")
+
+    def _build_pyramids(self, gray_image: np.ndarray, depth_image: np.ndarray):
+        """Uploads the current frame; pyramid (median3 + decimate) and packed Sobel planes are built on the
+        device.  The previous frame's pyramid is already resident."""
+        if not self._have_prev:
+            raise DVOError("no previous frame: call step() with the first frame before _build_pyramids()")
+        try:
+            self._ctx.upload_frame(self._cur_slot, gray_image, depth_image, self._levels)
+        except (_cabi.DVOHipError, ValueError) as e:
+            raise ImagePyramidError("Could not create Image Pyramid, got '{}'".format(e))
+        self._set_pyramid_views()
+
+    def _setup(self, level: int):
+        """Gradients are part of the packed planes built at upload; nothing to do per level."""
+        if not (0 <= level < self._levels):
+            raise IndexError("'level' out of range [0, {}], got {} instead".format(self._levels - 1, level))
+
+    def _cleanup(self):
+        pass
+
+    def compute_residuals_and_jacobian(self, estimate: Se3, level: int = 0
+                                       ) -> Tuple[np.ndarray, np.ndarray, np.ndarray]:
+        """Same return contract as the reference hook (cpu_robust...:134-200): residuals (N,1) f32,
+        jacobian (N,6) f32 over depth-valid AND in-bounds pixels, and the depth-valid mask (H,W) bool."""
+        r, J, valid, uv, (h, w) = self._ctx.residuals_jacobian(level, self._prev_slot, self._cur_slot,
+                                                               estimate.exp(), self._variant)
+        mask = ~np.isnan(uv[:, 0])          # depth != 0 (camera_model.py:195); quirk Q6: not the in-bounds test
+        residuals = r[valid].reshape(-1, 1)
+        jacobian = J[valid]
+        logger.debug("Intensity Residuals (min, max, mean): ({}, {}, {})".format(
+            residuals.min() if residuals.size else np.nan, residuals.max() if residuals.size else np.nan,
+            residuals.mean() if residuals.size else np.nan))
+        return residuals, jacobian, mask.reshape(h, w)
+
+    # -- added hook: device-side reduction ------------------------------------------------------------------
+    def compute_normal_equations(self, estimate: Se3, level: int = 0):
+        """-> H (6,6) f64, b (6,) f64 [= -J^T W r], err (float32 mean of w r^2), n_valid.
+        Fuses compute_residuals_and_jacobian + weighting + `H = Jt @ J; b = -Jt @ r`
+        (base_robust_dvo.py:166-188) in one kernel launch."""
+        T = estimate.exp()
+        ps, cs = [self._prev_slot], [self._cur_slot]
+        if self._weighting == "student_t_reference":
+            lam = self._student_t_lambda(level, T)
+            rec = self._ctx.normal_equations(level, ps, cs, T, self._variant, _cabi.WEIGHT_STUDENT_T, [lam])[0]
+        elif self._weighting == "huber":
+            k = np.finfo(np.float32).max if self._huber_sigma is None else self._huber_k * self._huber_sigma
+            rec = self._ctx.normal_equations(level, ps, cs, T, self._variant, _cabi.WEIGHT_HUBER, [k])[0]
+        else:
+            rec = self._ctx.normal_equations(level, ps, cs, T, self._variant, _cabi.WEIGHT_NONE, None)[0]
+        H, b, sum_wr2, n, sum_r2 = _cabi.unpack_record(rec)
+        if self._weighting == "huber":
+            self._huber_sigma = float(np.sqrt(sum_r2 / n)) if n else None
+        err = float(np.float32(sum_wr2 / n)) if n else float("nan")
+        return H, b, err, n
+
+    def _student_t_lambda(self, level: int, T: np.ndarray, dof: int = 5, initial_sigma: float = 5.0,
+                          tol: float = 1e-3, max_iter: int = 50) -> float:
+        """TDistributionWeighter.weight's IRLS loop (weighter/t_weighter.py:21-34) with the scale sums
+        computed on the device (one pass over the residuals per iteration)."""
+        last = 1.0 / (initial_sigma ** 2)
+        cur = last
+        for _ in range(max_iter):
+            sigma2 = float(self._ctx.weighted_r2_sum(level, [self._prev_slot], [self._cur_slot], T, [last],
+                                                     self._variant)[0])
+            cur = 1.0 / sigma2 if sigma2 != 0.0 else float("inf")
+            if abs(cur - last) < tol:
+                break
+            last = cur
+        return cur
+
+    # -- GN solver (base_robust_dvo.py:137-236) --------------------------------------------------------------
+    def _step(self, gray_image: np.ndarray, depth_image: np.ndarray, init_guess: Se3 = None):
+        if init_guess is None:
+            init_guess = Se3.identity()
+        self._build_pyramids(gray_image=gray_image, depth_image=depth_image)
+        if (self._curr_gray_image_pyr is None) or (self._curr_depth_image_pyr is None):
+            raise NotImplementedError("Call to _build_curr_pyramids did not correctly set pyramids")
+        if (self._prev_gray_image_pyr is None) or (self._prev_depth_image_pyr is None):
+            raise NotImplementedError("Call to _build_prev_pyramids did not correctly set pyramids")
+        return self._gauss_newton(init_guess)
+
+    def _gauss_newton(self, init_guess: Se3) -> Se3:
+        if self._solver == "device":
+            return self._gauss_newton_device(init_guess)
+        estimate = init_guess.copy()
+        self.last_iterations = 0
+        self._huber_sigma = None
+        for level in range(self._levels - 1, -1, -1):
+            err_prev = np.finfo("float32").max
+            err_increased_count = 0
+            self._setup(level=level)
+            for i in range(self._max_iter):
+                H, b, err, n = self.compute_normal_equations(estimate=estimate, level=level)
+                self.last_iterations += 1
+                if np.all(np.isfinite(H)) and np.all(np.isfinite(b)):
+                    inc_xi = scipy.linalg.lstsq(H, b.reshape(6, 1), lapack_driver="gelsy", check_finite=False)[0]
+                else:
+                    inc_xi = np.full((6, 1), np.nan)
+                inc = Se3.from_se3(inc_xi)
+                err_diff = err - err_prev
+                logger.debug("Iteration {} -> error: {:.4f}".format(i + 1, err))
+                if abs(err_diff) < self._tolerance:
+                    logger.info("Found convergence on iteration {} (error: {:.4f})".format(i + 1, err))
+                    break
+                if err_diff < 0.0:
+                    estimate = inc * estimate
+                    err_prev = err
+                    err_increased_count = 0
+                else:
+                    err_increased_count += 1
+                if err_increased_count > self._max_increased_steps_allowed:
+                    logger.info("Error increased on iteration '{}' (error: {:.4f})".format(i, err))
+                    break
+                if i == (self._max_iter - 1):
+                    logger.warning("Exceeded maximum number of iterations '{}' (error: {:.4f})".format(
+                        self._max_iter, err))
+            self._cleanup()
+        return estimate
+
+    def _gauss_newton_device(self, init_guess: Se3) -> Se3:
+        T0 = None
+        if not np.allclose(init_guess.exp(), np.eye(4)):
+            T0 = init_guess.exp()[None, :3, :]
+        wmode = _WEIGHTS[self._weighting]
+        res = self._ctx.solve_batch([self._prev_slot], [self._cur_slot], self._levels, self._max_iter,
+                                    self._tolerance, self._max_increased_steps_allowed, self._variant, wmode,
+                                    self._huber_k, T0)
+        self.last_iterations = int(res["iters"][0])
+        if not np.all(np.isfinite(res["T"][0])):
+            return None
+        return Se3.from_se3(res["xi"][0].reshape(6, 1))
+
+
+def robust_dvo_factory(use_gpu: bool = True, backend: str = "hip", **kwargs):
+    """Counterpart of core/robust_dense_visual_odometry/__init__.py:5-25.  This package ships one backend;
+    `use_gpu=False` / another backend name is an error rather than a silent CPU path."""
+    if backend != "hip" or not use_gpu:
+        raise ValueError("dvo_amd only provides the MI355X backend (backend='hip', use_gpu=True)")
+    return RobustDVOHIP(**kwargs)
+
+
+_SUPPORTED_METHODS = {"robust-dvo": robust_dvo_factory}
+
+
+def get_dvo(method: str, camera_model: RGBDCameraModel, init_pose: Se3, **kwargs):
+    """Factory with the reference's signature and error behaviour (core/__init__.py:14-40)."""
+    if method not in _SUPPORTED_METHODS.keys():
+        raise ValueError("Not supported method '{}', available options are '{}'".format(
+            method, list(_SUPPORTED_METHODS.keys())))
+    try:
+        result = _SUPPORTED_METHODS[method](camera_model=camera_model, initial_pose=init_pose, **kwargs)
+    except Exception as e:
+        raise ValueError((
+            "Could not dynamically load method '{}' with parameters '{}'".format(method, kwargs),
+            ", got the following exception: {}".format(e)))
+    return result

@@ -1,0 +1,167 @@
+/*
+ * dvo_hip.h — C ABI of the MI355X (gfx950) dense RGB-D direct-alignment core.
+ *
+ * This is the drop-in boundary for ONE path of pfontana96/dense-visual-odometry: the backend
+ * hooks of BaseRobustDVO and the few lines of its Gauss-Newton loop that consume them.
+ * Reference citations are relative to /root/reference/src/dense_visual_odometry/.
+ *
+ * Conventions
+ *   - plain C symbols, plain pointers and sizes; no C++/torch types cross the boundary;
+ *   - every function returns DVO_OK (0) or a negative dvo_status; nothing throws;
+ *     dvo_last_error(ctx) returns a human-readable message for the last failure on that ctx
+ *     (dvo_last_error(NULL): last failure of dvo_create on the calling thread);
+ *   - host pointers are owned by the caller and only need to be valid for the duration of the
+ *     call; the ctx owns all device memory and (unless dvo_set_stream is used) one HIP stream;
+ *   - one ctx per GPU; a ctx is not thread-safe, different ctxs are independent;
+ *   - there is NO CPU fallback: without a HIP device every entry point fails with
+ *     DVO_ERR_NO_DEVICE / DVO_ERR_HIP.
+ *
+ * Data model (device resident, per frame "slot", per pyramid level L of size w_L x h_L):
+ *   gray   u8  [h][w]            intensity (level 0 = caller's image, L>0 = median3 + 2x decimate)
+ *   depth  u16 [h][w]            raw depth (same pyramid rule)
+ *   packed u32 [h+1][pitch]      bits 0-7 intensity, bits 8-19 Sobel gx (signed 12 bit),
+ *                                bits 20-31 Sobel gy (signed 12 bit); one zero pad row/column so
+ *                                the 2x2 bilinear neighbourhood is always addressable
+ *
+ * Pose arguments `T` are row-major 3x4 float32 [R|t] (the top three rows of Se3.exp(),
+ * utils/lie_algebra/special_euclidean_group.py:35-52), one per frame pair.
+ *
+ * Normal-equation record (`out` of dvo_normal_equations, float64, DVO_NE_STRIDE = 32 per pair):
+ *   [0..20]  upper triangle of H = J^T W J, row-major (H00 H01 .. H05 H11 .. H55)
+ *   [21..26] J^T W r      (the caller negates: b = -J^T W r, base_robust_dvo.py:188)
+ *   [27]     sum w r^2    [28] number of valid pixels N    [29] sum r^2    [30..31] reserved (0)
+ */
+#ifndef DVO_HIP_H
+#define DVO_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct dvo_ctx dvo_ctx;
+
+typedef enum dvo_status {
+    DVO_OK = 0,
+    DVO_ERR_INVALID_ARG = -1,
+    DVO_ERR_NO_DEVICE = -2,
+    DVO_ERR_HIP = -3,
+    DVO_ERR_OUT_OF_MEMORY = -4,
+    DVO_ERR_BAD_STATE = -5      /* e.g. slot not uploaded, camera not set */
+} dvo_status;
+
+/* which of the reference's three behavioural variants of the residual/Jacobian path */
+typedef enum dvo_variant {
+    DVO_VARIANT_V1 = 0,  /* CPU default: Sobel grad of I2 sampled at the warped point, J_w at the un-warped
+                            point (cpu_robust_dense_visual_odometry.py:58,123-130,168-170) */
+    DVO_VARIANT_V2 = 1,  /* approximate_image2_gradient=True: Sobel grad of I1 at the pixel (:60-77,:187-188) */
+    DVO_VARIANT_V3 = 2   /* numba.cuda kernel: central-difference grad of I1, J_w at the WARPED point, strict
+                            bilinear bounds (cuda/residuals_kernel.py:46-109) */
+} dvo_variant;
+
+typedef enum dvo_weight_mode {
+    DVO_WEIGHT_NONE = 0,       /* use_weighter=False: w = 1 */
+    DVO_WEIGHT_STUDENT_T = 1,  /* w = 6 / (5 + r^2 * lambda); weight_param[pair] = lambda
+                                  (weighter/t_weighter.py:34) */
+    DVO_WEIGHT_HUBER = 2       /* build-defined: w = min(1, k/|r|); weight_param[pair] = k (grey levels) */
+} dvo_weight_mode;
+
+#define DVO_NE_STRIDE 32
+#define DVO_MAX_LEVELS 8
+
+/* ---- lifetime -------------------------------------------------------------------------------- */
+
+/* Creates a context on HIP device `device` with `n_slots` frame slots sized for max_w x max_h images and
+ * up to max_levels pyramid levels, and scratch for up to max_pairs frame pairs per call.
+ * Counterpart of RobustDVOGPU.__init__ pre-allocating its pyramids
+ * (core/robust_dense_visual_odometry/gpu_robust_dense_visual_odometry.py:17-47). */
+int dvo_create(int device, int max_w, int max_h, int max_levels, int n_slots, int max_pairs, dvo_ctx** out);
+void dvo_destroy(dvo_ctx* ctx);
+const char* dvo_last_error(const dvo_ctx* ctx);
+
+/* Launch all work of this ctx on an externally owned hipStream_t (e.g. torch's current stream).
+ * NULL restores the ctx's own stream. */
+int dvo_set_stream(dvo_ctx* ctx, void* hip_stream);
+int dvo_synchronize(dvo_ctx* ctx);
+
+/* ---- camera (camera_model.py:17-79) ------------------------------------------------------------ */
+
+/* Level-0 intrinsics; level L intrinsics follow RGBDCameraModel.at (camera_model.py:62-79). */
+int dvo_set_camera(dvo_ctx* ctx, float fx, float fy, float cx, float cy, float skew, double depth_scale);
+/* Writes the 3x4 float32 level intrinsics the kernels use (for tests / hosts that want to cross-check). */
+int dvo_get_level_intrinsics(const dvo_ctx* ctx, int level, float* k3x4);
+
+/* ---- frame ingest: replaces RobustDVOCPU._build_pyramids + _setup --------------------------------
+ * (cpu_robust_dense_visual_odometry.py:44-77; utils/image_pyramid.py:19-54; utils/jacobian.py:47-73) */
+
+/* Host images -> slot: H2D copy, then on device: (median3 + 2x decimate) per level for gray and depth,
+ * Sobel3x3/BORDER_REFLECT of every gray level packed with the intensity. */
+int dvo_upload_frame(dvo_ctx* ctx, int slot, const uint8_t* gray, const uint16_t* depth, int w, int h, int levels);
+/* Same, but gray/depth are DEVICE pointers already resident in HBM (async on the ctx stream). */
+int dvo_upload_frame_device(dvo_ctx* ctx, int slot, const void* d_gray, const void* d_depth, int w, int h, int levels);
+/* Colour ingest: BGR u8 [h][w][3] -> gray (OpenCV 8-bit fixed point) and depth clamp
+ * depth*depth_scale > max_distance -> 0, on device (core/base_dense_visual_odometry.py:58-59). */
+int dvo_upload_frame_bgr(dvo_ctx* ctx, int slot, const uint8_t* bgr, const uint16_t* depth, int w, int h, int levels,
+                         double max_distance);
+/* Copies one level of a slot back to the host (any pointer may be NULL). gx/gy are the unpacked Sobel planes. */
+int dvo_download_level(dvo_ctx* ctx, int slot, int level, uint8_t* gray, uint16_t* depth, int16_t* gx, int16_t* gy);
+int dvo_slot_info(const dvo_ctx* ctx, int slot, int* w, int* h, int* levels);
+
+/* ---- the hot path ------------------------------------------------------------------------------ */
+
+/* Fused residual + Jacobian + weight + 6x6 reduction for n_pairs frame pairs at one level: what
+ * compute_residuals_and_jacobian (cpu_robust...:134-200) followed by H = J^T W J, b = -J^T W r
+ * (base_robust_dvo.py:168-188) computes, without materialising r or J.  Blocks until `out` is valid. */
+int dvo_normal_equations(dvo_ctx* ctx, int level, int n_pairs, const int* prev_slot, const int* cur_slot,
+                         const float* T, int variant, int weight_mode, const double* weight_param, double* out);
+
+/* Student-t scale pass: out[pair] = sum_i r_i^2 * 6 / (5 + r_i^2 * lambda[pair])
+ * (TDistributionWeighter._compute_scale, weighter/t_weighter.py:36-47 — a sum, reference quirk Q3). */
+int dvo_weighted_r2_sum(dvo_ctx* ctx, int level, int n_pairs, const int* prev_slot, const int* cur_slot,
+                        const float* T, int variant, const double* lambda, double* out);
+
+/* Dense outputs with the return contract of compute_residuals_and_jacobian (API parity / debugging):
+ * r [h*w] (0 where invalid), J [h*w][6], valid [h*w] (depth != 0 AND warped point in bounds),
+ * uv [h*w][2] warped coordinates (NaN where depth == 0).  Any output pointer may be NULL. */
+int dvo_residuals_jacobian(dvo_ctx* ctx, int level, int prev_slot, int cur_slot, const float* T, int variant,
+                           float* r, float* J, uint8_t* valid, float* uv);
+
+/* Whole coarse-to-fine Gauss-Newton solve of n_pairs frame pairs on the device (BaseRobustDVO._step,
+ * base_robust_dvo.py:137-236, sigma prior off): per iteration one reduction launch and one tiny
+ * solve/update launch per batch, no host round trip; stop rules evaluated per pair on the device.
+ *   T_init  n_pairs x 12 or NULL (identity)          T_out   n_pairs x 12
+ *   xi_out  n_pairs x 6 float64 log of the estimate (may be NULL)
+ *   iters_out n_pairs (total GN iterations run, may be NULL)   err_out n_pairs (last accepted error, may be NULL) */
+int dvo_solve_batch(dvo_ctx* ctx, int n_pairs, const int* prev_slot, const int* cur_slot, int levels,
+                    int max_iterations, double tolerance, int max_increased_steps_allowed, int variant,
+                    int weight_mode, double weight_param, const float* T_init, float* T_out, double* xi_out,
+                    int* iters_out, double* err_out);
+/* Asynchronous form: enqueue only; results land in device buffers, fetched by dvo_solve_batch_fetch. */
+int dvo_solve_batch_enqueue(dvo_ctx* ctx, int n_pairs, const int* prev_slot, const int* cur_slot, int levels,
+                            int max_iterations, double tolerance, int max_increased_steps_allowed, int variant,
+                            int weight_mode, double weight_param, const float* T_init);
+int dvo_solve_batch_fetch(dvo_ctx* ctx, int n_pairs, float* T_out, double* xi_out, int* iters_out, double* err_out);
+
+/* Per-iteration trace of dvo_solve_batch (tests / debugging): enable with the number of iterations to keep
+ * per pair (0 disables).  Each record is DVO_TRACE_STRIDE doubles: the normal-equation record [0..31], the
+ * solved increment xi [32..37] and the 3x4 pose the iteration was evaluated at [38..49]. */
+#define DVO_TRACE_STRIDE 50
+int dvo_trace_enable(dvo_ctx* ctx, int max_iterations_traced);
+int dvo_trace_read(dvo_ctx* ctx, int n_pairs, double* out /* n_pairs x cap x DVO_TRACE_STRIDE */);
+
+/* ---- measurement ------------------------------------------------------------------------------- */
+
+/* When enabled, every launch of the reduction kernel is bracketed by HIP events on the ctx stream. */
+int dvo_profile_enable(dvo_ctx* ctx, int on);
+/* Sums since the last reset: per level, number of reduction launches, their total device time (ms)
+ * and total pixels / depth-valid pixels... read with n = DVO_MAX_LEVELS entries each. Blocks (syncs). */
+int dvo_profile_read(dvo_ctx* ctx, int64_t* launches, double* ms, int reset);
+/* Event-pair stopwatch on the ctx stream. */
+int dvo_timer_start(dvo_ctx* ctx);
+int dvo_timer_stop(dvo_ctx* ctx, float* ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DVO_HIP_H */

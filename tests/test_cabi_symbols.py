@@ -1,0 +1,56 @@
+"""CPU-side checks of the drop-in boundary: the shared library loads and exports every symbol that
+include/dvo_hip.h declares; without a GPU the entry points fail loudly (no CPU fallback)."""
+import ctypes
+import re
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+ROOT = Path(__file__).resolve().parents[1]
+
+
+def _declared_functions():
+    text = (ROOT / "include" / "dvo_hip.h").read_text()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(dvo_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_declares_expected_entry_points():
+    names = _declared_functions()
+    for must in ("dvo_create", "dvo_destroy", "dvo_set_camera", "dvo_upload_frame", "dvo_normal_equations",
+                 "dvo_weighted_r2_sum", "dvo_residuals_jacobian", "dvo_solve_batch", "dvo_last_error"):
+        assert must in names
+
+
+def test_library_exports_every_declared_symbol():
+    from dvo_amd import _cabi
+    lib = ctypes.CDLL(str(_cabi.library_path()))
+    for name in _declared_functions():
+        assert hasattr(lib, name), "libdvo_hip.so does not export {}".format(name)
+    # and the Python binding covers exactly the header
+    assert sorted(_cabi.SIGNATURES) == _declared_functions()
+
+
+def test_no_cpu_fallback_without_device():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    import dvo_amd
+    with pytest.raises(dvo_amd.DVOHipError) as e:
+        dvo_amd.HipContext()
+    assert e.value.code in (-2, -3)
+    cam = dvo_amd.RGBDCameraModel(np.eye(3, dtype=np.float32), 1.0)
+    with pytest.raises(ValueError):           # get_dvo wraps any constructor failure (core/__init__.py:32-38)
+        dvo_amd.get_dvo("robust-dvo", cam, dvo_amd.Se3.identity(), levels=1)
+    with pytest.raises(ValueError):
+        dvo_amd.get_dvo("kerl", cam, dvo_amd.Se3.identity(), levels=1)
+
+
+def test_product_package_does_not_import_the_oracle():
+    pkg = ROOT / "dense-visual-odometry_amd"
+    pat = re.compile(r"^\s*(import|from)\s+\S*oracle", re.M)
+    for path in pkg.rglob("*.py"):
+        assert not pat.search(path.read_text()), path
+    for path in list(pkg.rglob("*.hip")) + list(pkg.rglob("*.h")):
+        assert not re.search(r"#include\s+[\"<][^\">]*oracle", path.read_text()), path

@@ -1,0 +1,479 @@
+"""Parity tests proper: the HIP path, called through the C ABI, against the CPU oracle and the golden
+vectors of the reference run — on the same inputs.  Run on the GPU box with `pytest -m gpu`.
+
+Tolerances (stated by BASELINE.json north_star): SE(3) increments within 1e-5 relative; everything that is
+integer / index work (pyramids, Sobel planes, validity masks, warped coordinates) is bit-exact.
+"""
+import numpy as np
+import pytest
+import scipy.linalg
+
+import dvo_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def _rel(a, b):
+    return float(np.linalg.norm(np.asarray(a, dtype=np.float64) - np.asarray(b, dtype=np.float64)) /
+                 max(np.linalg.norm(np.asarray(b, dtype=np.float64)), 1e-300))
+
+
+def _solve(H, b):
+    return scipy.linalg.lstsq(H, b.reshape(6, 1), lapack_driver="gelsy")[0].reshape(6)
+
+
+@pytest.fixture(scope="module")
+def hip(frames):
+    """One context holding the ten fixture frames (4 pyramid levels) in slots 0..9."""
+    import dvo_amd
+    from dvo_amd import _cabi
+    ctx = dvo_amd.HipContext(device=0, max_w=640, max_h=480, max_levels=4, n_slots=12, max_pairs=16)
+    K = frames["K"]
+    ctx.set_camera(K[0, 0], K[1, 1], K[0, 2], K[1, 2], K[0, 1], frames["depth_scale"])
+    for i in range(10):
+        ctx.upload_frame(i, frames["gray"][i], frames["depth"][i], 4)
+    yield ctx, _cabi
+    ctx.close()
+
+
+@pytest.fixture(scope="module")
+def pyramids(frames):
+    cache = {}
+
+    def get(k):
+        if k not in cache:
+            cache[k] = (O.build_pyramid(frames["gray"][k], 4), O.build_pyramid(frames["depth"][k], 4))
+        return cache[k]
+    return get
+
+
+def _level(frames, pyramids, k, lvl):
+    gp, dp = pyramids(k)
+    gc, _ = pyramids(k + 1)
+    return O.PairLevel(gp[lvl], dp[lvl], gc[lvl], O.level_intrinsics(frames["K"], lvl), frames["depth_scale"])
+
+
+# ------------------------------------------------------------------------------------------------
+# setup kernels: pyramid (K1) + Sobel pack (K2) — bit exact
+# ------------------------------------------------------------------------------------------------
+def test_device_pyramid_and_gradients_bit_exact(hip, frames, pyramids):
+    ctx, _ = hip
+    for slot in (0, 1, 7):
+        gp, dp = pyramids(slot)
+        for lvl in range(4):
+            d = ctx.download_level(slot, lvl)
+            assert np.array_equal(d["gray"], gp[lvl])
+            assert np.array_equal(d["depth"], dp[lvl])
+            gx, gy = O.sobel3(gp[lvl])
+            assert np.array_equal(d["gx"].astype(np.float32), gx)
+            assert np.array_equal(d["gy"].astype(np.float32), gy)
+
+
+def test_level_intrinsics_bit_exact(hip, frames):
+    ctx, _ = hip
+    for lvl in range(5):
+        assert np.array_equal(ctx.level_intrinsics(lvl), frames["level_intrinsics"][lvl])
+
+
+def test_pyramid_odd_and_tiny_sizes():
+    import dvo_amd
+    rng = np.random.default_rng(3)
+    for (h, w, levels) in ((37, 53, 3), (9, 7, 2), (1, 1, 1), (2, 130, 2)):
+        gray = rng.integers(0, 256, size=(h, w), dtype=np.uint8)
+        depth = rng.integers(0, 65536, size=(h, w)).astype(np.uint16)
+        with dvo_amd.HipContext(max_w=w, max_h=h, max_levels=levels, n_slots=2, max_pairs=1) as ctx:
+            ctx.upload_frame(0, gray, depth, levels)
+            gp, dp = O.build_pyramid(gray, levels), O.build_pyramid(depth, levels)
+            for lvl in range(levels):
+                d = ctx.download_level(0, lvl)
+                assert np.array_equal(d["gray"], gp[lvl]) and np.array_equal(d["depth"], dp[lvl])
+                gx, gy = O.sobel3(gp[lvl])
+                assert np.array_equal(d["gx"], gx.astype(np.int16)) and np.array_equal(d["gy"], gy.astype(np.int16))
+
+
+def test_bgr_ingest_matches_oracle(frames):
+    import dvo_amd
+    bgr = frames["color_bgr_1"]
+    depth = frames["depth"][0].copy()
+    depth[100:120, 200:260] = 40000            # 8 m > max_distance -> zeroed on the device
+    with dvo_amd.HipContext(max_w=640, max_h=480, max_levels=2, n_slots=2, max_pairs=1) as ctx:
+        ctx.set_camera(500, 500, 320, 240, 0, frames["depth_scale"])
+        ctx.upload_frame_bgr(0, bgr, depth, 2, 5.0)
+        d = ctx.download_level(0, 0, want=("gray", "depth"))
+    assert np.array_equal(d["gray"], O.bgr2gray(bgr))
+    assert np.array_equal(d["gray"], frames["gray"][0])
+    exp = depth.copy()
+    exp[(exp * frames["depth_scale"]) > 5.0] = 0
+    assert np.array_equal(d["depth"], exp) and (d["depth"][100:120, 200:260] == 0).all()
+
+
+# ------------------------------------------------------------------------------------------------
+# K5 dense writer: validity + warped coordinates bit exact, r / J to float32 rounding
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("lvl,tag", [(3, "id"), (3, "xi"), (2, "id"), (2, "xi")])
+def test_dense_residuals_jacobian_vs_golden_and_oracle(hip, frames, pyramids, golden_dir, lvl, tag):
+    ctx, cabi = hip
+    g = np.load(golden_dir / "dense_rj.npz")
+    pre = "l%d_%s_" % (lvl, tag)
+    T = g[pre + "T"]
+    r, J, valid, uv, (h, w) = ctx.residuals_jacobian(lvl, 0, 1, T)
+    lv = _level(frames, pyramids, 0, lvl)
+    ro, Jo, mask_o, valid_o = O.residuals_and_jacobian(lv, T)
+    # integer / index work: bit exact
+    assert np.array_equal(valid.reshape(h, w), valid_o)
+    assert np.array_equal(~np.isnan(uv[:, 0]).reshape(h, w), g[pre + "mask"])
+    x, y, z, m = O.deproject(lv.depth_prev, lv.KL, lv.depth_scale)
+    uo, vo = O.project(lv.KL, *O.transform_points(T, x, y, z))
+    assert np.array_equal(uv[m.reshape(-1), 0], uo) and np.array_equal(uv[m.reshape(-1), 1], vo)
+    # float work
+    assert r[valid].shape[0] == g[pre + "r"].shape[0]
+    np.testing.assert_allclose(r[valid], g[pre + "r"].reshape(-1), rtol=0, atol=1e-4)
+    np.testing.assert_allclose(r[valid], ro.reshape(-1), rtol=0, atol=1e-4)
+    scale = np.abs(g[pre + "J"]).max(axis=0)
+    np.testing.assert_allclose(J[valid] / scale, g[pre + "J"] / scale, rtol=0, atol=2e-6)
+    assert (r[~valid] == 0).all() and (J[~valid] == 0).all()
+
+
+def test_dense_variant_v2_vs_oracle(hip, frames, pyramids):
+    ctx, cabi = hip
+    T = O.Pose.from_xi(np.array([0.002, -0.007, -0.011, 0.005, 0.0065, 0.0034])).matrix()
+    r, J, valid, uv, (h, w) = ctx.residuals_jacobian(2, 0, 1, T, variant=cabi.VARIANT_V2)
+    ro, Jo, _, valid_o = O.residuals_and_jacobian(_level(frames, pyramids, 0, 2), T, "v2")
+    assert np.array_equal(valid.reshape(h, w), valid_o)
+    np.testing.assert_allclose(r[valid], ro.reshape(-1), rtol=0, atol=1e-4)
+    scale = np.abs(Jo).max(axis=0)
+    np.testing.assert_allclose(J[valid] / scale, Jo / scale, rtol=0, atol=2e-6)
+
+
+# ------------------------------------------------------------------------------------------------
+# K3 fused reduction: normal equations / increments, teacher-forced with the reference run's poses
+# ------------------------------------------------------------------------------------------------
+def test_increments_all_pairs_all_iterations_vs_reference_run(hip, frames, golden_dir):
+    """All 356 GN iterations of the nine fixture pairs (4 levels x 10 iterations)."""
+    ctx, cabi = hip
+    g = np.load(golden_dir / "pairs_l4.npz")
+    worst = 0.0
+    for lvl in range(4):
+        idx = np.flatnonzero(g["level"] == lvl)
+        for s in range(0, len(idx), 16):
+            sel = idx[s:s + 16]
+            prev = g["pair"][sel].astype(np.int32)
+            rec = ctx.normal_equations(lvl, prev, prev + 1, g["T"][sel])
+            for j, i in enumerate(sel):
+                H, b, swr2, n, sr2 = cabi.unpack_record(rec[j])
+                assert n == int(g["n"][i])                               # validity: bit exact
+                inc = _solve(H, b)
+                e = _rel(inc, g["inc64"][i])
+                worst = max(worst, e)
+                assert e < 1e-5, (i, e)
+                assert _rel(H, g["H64"][i]) < 1e-6 and _rel(b, g["b64"][i]) < 5e-6
+                assert abs(swr2 - g["sum_r2"][i]) <= 1e-6 * g["sum_r2"][i]
+    assert worst < 2e-6
+
+
+def test_increments_single_level_trace(hip, frames, golden_dir):
+    ctx, cabi = hip
+    g = np.load(golden_dir / "single_l1.npz")
+    for i in range(0, len(g["level"]), 3):
+        rec = ctx.normal_equations(0, [0], [1], g["T"][i:i + 1])[0]
+        H, b, swr2, n, _ = cabi.unpack_record(rec)
+        assert n == int(g["n"][i])
+        assert _rel(_solve(H, b), g["inc64"][i]) < 1e-5
+
+
+def test_normal_equations_vs_oracle_random_poses(hip, frames, pyramids):
+    ctx, cabi = hip
+    rng = np.random.default_rng(11)
+    for trial in range(6):
+        k = int(rng.integers(0, 9))
+        lvl = int(rng.integers(0, 4))
+        xi = rng.normal(0, 1, 6) * np.array([0.02, 0.02, 0.02, 0.01, 0.01, 0.01])
+        T = O.Pose.from_xi(xi).matrix()
+        rec = ctx.normal_equations(lvl, [k], [k + 1], T[None])[0]
+        H, b, swr2, n, sr2 = cabi.unpack_record(rec)
+        r, J, _, _ = O.residuals_and_jacobian(_level(frames, pyramids, k, lvl), T)
+        Ho, bo, so, no = O.normal_equations(r, J)
+        assert n == no
+        assert _rel(H, Ho) < 1e-6 and _rel(b, bo) < 5e-6 and abs(swr2 - so) < 1e-6 * so
+        assert _rel(_solve(H, b), O.solve_increment(Ho, bo)) < 1e-5
+        assert swr2 == sr2
+
+
+def test_batched_call_equals_single_calls_bitwise(hip, golden_dir):
+    ctx, cabi = hip
+    g = np.load(golden_dir / "pairs_l4.npz")
+    sel = np.flatnonzero(g["level"] == 1)[:12]
+    prev = g["pair"][sel].astype(np.int32)
+    batch = ctx.normal_equations(1, prev, prev + 1, g["T"][sel])
+    for j, i in enumerate(sel):
+        one = ctx.normal_equations(1, prev[j:j + 1], prev[j:j + 1] + 1, g["T"][i:i + 1])
+        assert np.array_equal(one[0], batch[j])          # fixed-order reduction: deterministic
+    again = ctx.normal_equations(1, prev, prev + 1, g["T"][sel])
+    assert np.array_equal(again, batch)
+
+
+def test_student_t_reference_weights(hip, frames, pyramids, golden_dir):
+    ctx, cabi = hip
+    g = np.load(golden_dir / "weighted_l4.npz")
+    for i in range(0, len(g["level"]), 3):
+        lvl = int(g["level"][i])
+        T = g["T"][i:i + 1]
+        r, J, _, _ = O.residuals_and_jacobian(_level(frames, pyramids, 0, lvl), T[0])
+        r2 = (r * r).astype(np.float64).reshape(-1)
+        # scale pass (weighter/t_weighter.py:36-47)
+        for lam in (1.0 / 25.0, 1.0 / O.student_t_scale_sum(r2, 1.0 / 25.0)):
+            s = ctx.weighted_r2_sum(lvl, [0], [1], T, [lam])[0]
+            assert abs(s - O.student_t_scale_sum(r2, lam)) <= 2e-6 * s
+        w, lam = O.student_t_weights(r)
+        rec = ctx.normal_equations(lvl, [0], [1], T, cabi.VARIANT_V1, cabi.WEIGHT_STUDENT_T, [lam])[0]
+        H, b, swr2, n, sr2 = cabi.unpack_record(rec)
+        assert n == int(g["n"][i])
+        assert _rel(_solve(H, b), g["inc64"][i]) < 1e-5
+        assert abs(swr2 - g["sum_wr2"][i]) <= 2e-6 * g["sum_wr2"][i]
+
+
+def test_variant_v2_increments(hip, golden_dir):
+    ctx, cabi = hip
+    g = np.load(golden_dir / "approx_l4.npz")
+    for i in range(0, len(g["level"]), 3):
+        rec = ctx.normal_equations(int(g["level"][i]), [0], [1], g["T"][i:i + 1], cabi.VARIANT_V2)[0]
+        H, b, _, n, _ = cabi.unpack_record(rec)
+        assert n == int(g["n"][i])
+        assert _rel(_solve(H, b), g["inc64"][i]) < 1e-5
+
+
+def test_huber_weights_vs_oracle(hip, frames, pyramids):
+    """Build-defined weight (the reference has no Huber): parity against the oracle only."""
+    ctx, cabi = hip
+    T = np.eye(4, dtype=np.float32)
+    r, J, _, _ = O.residuals_and_jacobian(_level(frames, pyramids, 2, 1), T)
+    k = 1.345 * float(np.sqrt(np.mean(r.astype(np.float64) ** 2)))
+    Ho, bo, so, no = O.normal_equations(r, J, O.huber_weights(r, k))
+    rec = ctx.normal_equations(1, [2], [3], T[None], cabi.VARIANT_V1, cabi.WEIGHT_HUBER, [k])[0]
+    H, b, swr2, n, sr2 = cabi.unpack_record(rec)
+    assert n == no and _rel(H, Ho) < 1e-6 and _rel(_solve(H, b), O.solve_increment(Ho, bo)) < 1e-5
+    assert abs(swr2 - so) < 1e-6 * so
+
+
+# ------------------------------------------------------------------------------------------------
+# full Gauss-Newton: host-solve mode (north-star literal) and device-solve mode
+# ------------------------------------------------------------------------------------------------
+def _make_dvo(frames, **kw):
+    import dvo_amd
+    cam = dvo_amd.RGBDCameraModel(frames["K"], frames["depth_scale"])
+    return dvo_amd.get_dvo("robust-dvo", cam, dvo_amd.Se3.identity(), **kw), dvo_amd
+
+
+@pytest.mark.parametrize("solver", ["host", "device"])
+def test_step_api_four_levels_vs_reference_run(frames, golden_dir, solver):
+    g = np.load(golden_dir / "pairs_l4.npz")
+    dvo, _ = _make_dvo(frames, levels=4, max_iterations=10, solver=solver)
+    for k in (0, 1):
+        c = np.repeat(frames["gray"][k][..., None], 3, axis=2)
+        tf = dvo.step(c, frames["depth"][k].copy())
+        if k == 0:
+            np.testing.assert_array_equal(tf.exp(), np.eye(4, dtype=np.float32))
+    assert dvo.last_iterations == 40
+    np.testing.assert_allclose(tf.log().reshape(6), g["final_xi"][0], rtol=0, atol=5e-7)
+    np.testing.assert_allclose(tf.exp(), g["final_T"][0], rtol=0, atol=5e-7)
+
+
+def test_single_level_to_convergence_host(frames, golden_dir):
+    g = np.load(golden_dir / "single_l1.npz")
+    dvo, _ = _make_dvo(frames, levels=1)
+    dvo.step_gray(frames["gray"][0], frames["depth"][0])
+    tf = dvo.step_gray(frames["gray"][1], frames["depth"][1])
+    assert dvo.last_iterations == len(g["level"])
+    np.testing.assert_allclose(tf.log().reshape(6), g["final_xi"], rtol=0, atol=5e-7)
+
+
+def test_device_solve_batch_nine_pairs(hip, frames, golden_dir):
+    """dvo_solve_batch: nine pairs in one batch, stop rules per pair on the device (pair 7 stops early)."""
+    ctx, cabi = hip
+    g = np.load(golden_dir / "pairs_l4.npz")
+    prev = np.arange(9, dtype=np.int32)
+    ctx.trace_enable(40)
+    res = ctx.solve_batch(prev, prev + 1, levels=4, max_iterations=10)
+    for k in range(9):
+        assert res["iters"][k] == int((g["pair"] == k).sum())
+        np.testing.assert_allclose(res["xi"][k], g["final_xi"][k], rtol=0, atol=5e-7)
+        np.testing.assert_allclose(res["T"][k], g["final_T"][k][:3], rtol=0, atol=5e-7)
+    # per-iteration trace: increments of the free-running device loop vs the reference run's
+    tr = ctx.trace_read(9)
+    for k in range(9):
+        sel = np.flatnonzero(g["pair"] == k)
+        for j, i in enumerate(sel):
+            assert int(round(tr[k, j, 28])) == int(g["n"][i])
+            assert _rel(tr[k, j, 32:38], g["inc64"][i]) < 2e-4      # poses drift by ~1e-8 between the two runs
+    ctx.trace_enable(0)
+
+
+def test_device_solve_student_t_and_v2(hip, golden_dir):
+    ctx, cabi = hip
+    gw = np.load(golden_dir / "weighted_l4.npz")
+    res = ctx.solve_batch([0], [1], levels=4, max_iterations=10, weight_mode=cabi.WEIGHT_STUDENT_T)
+    assert res["iters"][0] == len(gw["level"])
+    np.testing.assert_allclose(res["xi"][0], gw["final_xi"], rtol=0, atol=1e-6)
+    ga = np.load(golden_dir / "approx_l4.npz")
+    res = ctx.solve_batch([0], [1], levels=4, max_iterations=10, variant=cabi.VARIANT_V2)
+    assert res["iters"][0] == len(ga["level"])
+    np.testing.assert_allclose(res["xi"][0], ga["final_xi"], rtol=0, atol=1e-6)
+
+
+def test_sequence_pose_chain_vs_reference_run(frames, golden_dir):
+    """step() over the ten fixture frames: current_pose chain (base_dense_visual_odometry.py:79)."""
+    import dvo_amd
+    g = np.load(golden_dir / "sequence.npz")
+    cam = dvo_amd.RGBDCameraModel(frames["K"], frames["depth_scale"])
+    T0 = frames["gt_T"][0]
+    init = dvo_amd.Se3(dvo_amd.So3(T0[:3, :3]), T0[:3, 3].reshape(3, 1))
+    dvo = dvo_amd.get_dvo("robust-dvo", cam, init, levels=4, max_iterations=10)
+    for k in range(10):
+        c = np.repeat(frames["gray"][k][..., None], 3, axis=2)
+        tf = dvo.step(c, frames["depth"][k].copy())
+        np.testing.assert_allclose(tf.exp(), g["tf_T"][k], rtol=0, atol=1e-6)
+        np.testing.assert_allclose(dvo.current_pose.exp(), g["pose_T"][k], rtol=0, atol=5e-6)
+
+
+# ------------------------------------------------------------------------------------------------
+# the reference's own tests for this path, through the drop-in API
+# ------------------------------------------------------------------------------------------------
+def test_reference_known_answer_10x10(golden_dir):
+    # reference test_cpu_robust_dense_visual_odometry.py:20-44
+    import dvo_amd
+    height, width = 10, 10
+    gray = np.full((height, width), 150, dtype=np.uint8)
+    gray[:5, :5] = 150 / 3.0
+    color = np.full((height, width, 3), 150, dtype=np.uint8)
+    color[:5, :5, :] = 150 / 3.0
+    depth = np.ones_like(gray).astype(np.uint16)
+    depth[:5, :5] = 3
+    cam = dvo_amd.RGBDCameraModel(np.eye(3, dtype=np.float32), 1.0)
+    dvo = dvo_amd.get_dvo("robust-dvo", cam, dvo_amd.Se3.identity(), levels=1, height=10, width=10)
+    dvo.step(color_image=color, depth_image=depth)
+    dvo._build_pyramids(gray_image=gray, depth_image=depth)
+    dvo._setup(level=0)
+    residuals, J, mask = dvo.compute_residuals_and_jacobian(estimate=dvo_amd.Se3.identity(), level=0)
+    np.testing.assert_almost_equal(residuals, np.zeros((100, 1), dtype=np.float32))
+    t = np.load(golden_dir / "tiny10.npz")
+    assert J.shape == (100, 6) and mask.all()
+    np.testing.assert_allclose(J, t["J"], rtol=1e-6, atol=1e-6)
+    # a constant image gives H = 0: gelsy's minimum-norm answer is a zero increment, on host and device
+    dvo2 = dvo_amd.get_dvo("robust-dvo", cam, dvo_amd.Se3.identity(), levels=1, height=10, width=10, solver="device")
+    flat = np.full((10, 10, 3), 90, dtype=np.uint8)
+    dvo2.step(flat, depth.copy())
+    tf = dvo2.step(flat, depth.copy())
+    np.testing.assert_array_equal(tf.log(), np.zeros((6, 1), dtype=np.float32))
+
+
+@pytest.mark.parametrize("idx", [4, 5])
+def test_reference_ground_truth_pose_residuals(frames, idx):
+    # reference test_cpu_robust_dense_visual_odometry.py:46-73
+    import dvo_amd
+    cam = dvo_amd.RGBDCameraModel(frames["K"], frames["depth_scale"])
+    T0, T1 = frames["gt_T"][idx - 1], frames["gt_T"][idx]
+    s0 = dvo_amd.Se3(dvo_amd.So3(T0[:3, :3]), T0[:3, 3].reshape(3, 1))
+    s1 = dvo_amd.Se3(dvo_amd.So3(T1[:3, :3]), T1[:3, 3].reshape(3, 1))
+    gt = s1.inverse() * s0
+    dvo = dvo_amd.get_dvo("robust-dvo", cam, s0, levels=1)
+    dvo.step_gray(frames["gray"][idx - 1], frames["depth"][idx - 1])
+    dvo._build_pyramids(gray_image=frames["gray"][idx], depth_image=frames["depth"][idx])
+    dvo._setup(level=0)
+    residuals, _, _ = dvo.compute_residuals_and_jacobian(estimate=gt, level=0)
+    assert np.isclose(residuals.mean(), 0.0, atol=5.0)
+    assert residuals.std() < 20
+
+
+# ------------------------------------------------------------------------------------------------
+# error behaviour of the boundary
+# ------------------------------------------------------------------------------------------------
+def test_error_codes(hip, frames):
+    ctx, cabi = hip
+    import dvo_amd
+    T = np.eye(4, dtype=np.float32)[None]
+    with pytest.raises(dvo_amd.DVOHipError) as e:
+        ctx.normal_equations(0, [0], [11], T)              # slot 11 never uploaded
+    assert e.value.code == -5
+    with pytest.raises(dvo_amd.DVOHipError) as e:
+        ctx.normal_equations(4, [0], [1], T)               # level not built
+    assert e.value.code == -1
+    with pytest.raises(dvo_amd.DVOHipError) as e:
+        ctx.normal_equations(0, [0], [1], T, variant=cabi.VARIANT_V3)
+    assert e.value.code == -1
+    with pytest.raises(dvo_amd.DVOHipError):
+        ctx.normal_equations(0, [0] * 17, [1] * 17, np.repeat(T, 17, axis=0))      # > max_pairs
+    with pytest.raises(dvo_amd.DVOHipError):
+        ctx.upload_frame(0, np.zeros((481, 640), np.uint8), np.zeros((481, 640), np.uint16), 4)
+    ctx.upload_frame(0, frames["gray"][0], frames["depth"][0], 4)                     # restore slot 0
+    with dvo_amd.HipContext(max_w=64, max_h=48, max_levels=2, n_slots=2, max_pairs=1) as c2:
+        c2.upload_frame(0, np.zeros((48, 64), np.uint8), np.ones((48, 64), np.uint16), 2)
+        c2.upload_frame(1, np.zeros((48, 64), np.uint8), np.ones((48, 64), np.uint16), 2)
+        with pytest.raises(dvo_amd.DVOHipError) as e:
+            c2.normal_equations(0, [0], [1], T)            # camera not set
+        assert e.value.code == -5
+
+
+def test_all_depth_invalid_gives_empty_system(frames):
+    import dvo_amd
+    from dvo_amd import _cabi
+    with dvo_amd.HipContext(max_w=64, max_h=48, max_levels=1, n_slots=2, max_pairs=1) as ctx:
+        ctx.set_camera(60, 60, 32, 24, 0, 0.001)
+        g = np.random.default_rng(0).integers(0, 255, size=(48, 64), dtype=np.uint8)
+        ctx.upload_frame(0, g, np.zeros((48, 64), np.uint16), 1)
+        ctx.upload_frame(1, g, np.zeros((48, 64), np.uint16), 1)
+        rec = ctx.normal_equations(0, [0], [1], np.eye(4, dtype=np.float32)[None])[0]
+        assert (rec == 0).all()
+        res = ctx.solve_batch([0], [1], levels=1, max_iterations=5)
+        assert res["iters"][0] == 1 and np.all(res["xi"][0] == 0)
+
+
+# ------------------------------------------------------------------------------------------------
+# BASELINE full sizes: size-independent properties (the oracle is too slow to sweep these)
+# ------------------------------------------------------------------------------------------------
+def _synthetic_frame(rng, h, w):
+    yy, xx = np.mgrid[0:h, 0:w].astype(np.float32)
+    img = np.zeros((h, w), np.float32)
+    for o in range(5):
+        f = 2.0 ** o
+        img += rng.uniform(0.3, 1.0) * np.sin(xx * f * 0.011 + rng.uniform(0, 6)) * np.cos(yy * f * 0.013 + rng.uniform(0, 6)) / f ** 0.5
+    img = (255 * (img - img.min()) / (img.max() - img.min())).astype(np.uint8)
+    depth = (5000 + 3000 * np.sin(xx * 0.004) * np.cos(yy * 0.005) + 4000).astype(np.uint16)
+    depth[rng.random((h, w)) < 0.2] = 0
+    depth[:16], depth[-16:], depth[:, :16], depth[:, -16:] = 0, 0, 0, 0
+    return img, depth
+
+
+def test_full_size_1280x960_properties():
+    import dvo_amd
+    from dvo_amd import _cabi
+    rng = np.random.default_rng(1234)
+    h, w, levels = 960, 1280, 5
+    img, depth = _synthetic_frame(rng, h, w)
+    with dvo_amd.HipContext(max_w=w, max_h=h, max_levels=levels, n_slots=4, max_pairs=4) as ctx:
+        ctx.set_camera(1034.6, 1033.0, 637.2, 479.0, 0.0, 0.0002)
+        ctx.upload_frame(0, img, depth, levels)
+        ctx.upload_frame(1, img, depth, levels)
+        I = np.eye(4, dtype=np.float32)[None]
+        for lvl in range(levels):
+            # (a) identical frames + identity pose: zero residual, zero gradient of the cost, N = valid count
+            rec = ctx.normal_equations(lvl, [0], [1], I)[0]
+            H, b, swr2, n, sr2 = _cabi.unpack_record(rec)
+            d = ctx.download_level(0, lvl, want=("depth",))["depth"]
+            r, J, valid, uv, _ = ctx.residuals_jacobian(lvl, 0, 1, I[0])
+            assert n == int(valid.sum()) <= int((d != 0).sum())
+            assert swr2 < 1e-6 * max(n, 1) and np.abs(b).max() <= 1e-6 * np.sqrt(np.diag(H)).max() * max(n, 1) ** 0.5
+            # (b) the fused reduction equals the float64 sum of the dense kernel's rows
+            J64 = J[valid].astype(np.float64)
+            assert _rel(H, J64.T @ J64) < 1e-6
+            # (c) H symmetric positive semi-definite
+            assert np.linalg.eigvalsh(H).min() > -1e-9 * np.abs(H).max()
+        # (d) weights: student-t with lambda -> 0 is 1.2 x the unweighted system; huber with huge k is unweighted
+        T = O.Pose.from_xi(np.array([0.004, -0.003, 0.002, 0.002, -0.001, 0.003])).matrix()[None]
+        r0 = ctx.normal_equations(0, [0], [1], T)[0]
+        rt = ctx.normal_equations(0, [0], [1], T, _cabi.VARIANT_V1, _cabi.WEIGHT_STUDENT_T, [0.0])[0]
+        rh = ctx.normal_equations(0, [0], [1], T, _cabi.VARIANT_V1, _cabi.WEIGHT_HUBER, [1e30])[0]
+        np.testing.assert_allclose(rt[:28], 1.2 * r0[:28], rtol=1e-6)
+        np.testing.assert_allclose(rh[:28], r0[:28], rtol=1e-12)
+        # (e) a solve from a perturbed start on identical frames walks back towards the identity
+        res = ctx.solve_batch([0], [1], levels=levels, max_iterations=10, T_init=T)
+        assert np.linalg.norm(res["xi"][0]) < 0.2 * np.linalg.norm([0.004, -0.003, 0.002, 0.002, -0.001, 0.003])
