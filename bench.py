@@ -1,0 +1,200 @@
+#!/usr/bin/env python3
+"""bench.py — frame-pairs/s of the full coarse-to-fine Gauss-Newton solve on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+One "step" = one pass of the hot path over one batch of synthetic RGB-D input per GPU: for a window of
+B+1 consecutive VGA frames already resident in HBM, build the pyramids + packed Sobel planes on the
+device, then run the whole 4-level x 10-iteration Gauss-Newton solve of the B frame pairs on the device
+(BASELINE.json configs[1]: 640x480, 4-level pyramid, 10 GN iterations/level; synthetic stream of that
+shape, since TUM fr1/desk is not on disk).  Each rank owns an independent stream (weak scaling);
+the per-pair pose records are all-gathered over RCCL inside the timed region.
+
+The JSON line also carries
+  roofline     — the dominant kernel (level-0 k_reduce): algorithmic bytes of SURVEY 8d (2P + 10V per pair
+                 per launch, with the measured V) / its average duration from HIP events on its own stream
+  cpu_baseline — the NumPy oracle (a port of the reference CPU path) timed on this host on a bounded sample.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT / "dense-visual-odometry_amd"))
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s spec, ~6.3 achievable)
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=128, help="frame pairs per GPU per step")
+    ap.add_argument("--width", type=int, default=640)
+    ap.add_argument("--height", type=int, default=480)
+    ap.add_argument("--levels", type=int, default=4)
+    ap.add_argument("--iterations", type=int, default=10)
+    ap.add_argument("--weighting", default="none", choices=["none", "student_t_reference", "huber"])
+    ap.add_argument("--distinct", type=int, default=0, help="distinct rendered frames (0 = batch+1)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-pairs", type=int, default=8)
+    return ap.parse_args()
+
+
+def cpu_baseline(stream_np, levels, iterations, n_pairs):
+    """Oracle (NumPy port of the reference CPU path, float32 J^T J like the reference) on a bounded sample."""
+    sys.path.insert(0, str(ROOT / "oracle"))
+    import dvo_oracle as O
+    try:
+        from threadpoolctl import threadpool_limits
+        limiter = threadpool_limits(limits=1)
+    except Exception:          # pragma: no cover
+        limiter = None
+    g, d = stream_np["gray"], stream_np["depth"]
+    n_pairs = min(n_pairs, g.shape[0] - 1)
+    O.gauss_newton(g[0], d[0], g[1], stream_np["K"], stream_np["depth_scale"], levels=levels,
+                   max_iterations=1, accumulate="fp32")                      # warm-up
+    t0 = time.perf_counter()
+    for k in range(n_pairs):
+        O.gauss_newton(g[k], d[k], g[k + 1], stream_np["K"], stream_np["depth_scale"], levels=levels,
+                       max_iterations=iterations, accumulate="fp32")
+    dt = time.perf_counter() - t0
+    if limiter is not None:
+        limiter.unregister() if hasattr(limiter, "unregister") else None
+    return {"value": n_pairs / dt, "unit": "frame-pairs/s", "cores": 1, "kind": "port",
+            "sample": "%d VGA frame pairs x %d levels x %d GN iterations, NumPy oracle (float32 J^T J), 1 thread, "
+                      "%.1f s; host has %d logical CPUs" % (n_pairs, levels, iterations, dt, os.cpu_count() or 0)}
+
+
+def main():
+    args = parse_args()
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if rank == 0:
+            print("warning: --gpus %d but WORLD_SIZE=%d; using WORLD_SIZE" % (args.gpus, world), file=sys.stderr)
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device (no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+
+    from dvo_amd import synthetic
+    from dvo_amd.batch import BatchAligner, pose_records, allgather_poses
+
+    B, W, H, L = args.batch, args.width, args.height, args.levels
+    n_frames = B + 1
+    n_distinct = args.distinct if args.distinct > 0 else n_frames
+    # independent stream per rank (BASELINE config 5), rendered on the device, resident in HBM before timing
+    st = synthetic.make_stream(min(n_distinct, n_frames), W, H, seed=1000 + rank, device="cuda", as_torch=True)
+    gray, depth = st["gray"], st["depth"]
+    if gray.shape[0] < n_frames:                      # optional: tile a shorter render (documented in config)
+        reps = (n_frames + gray.shape[0] - 1) // gray.shape[0]
+        gray = gray.repeat(reps, 1, 1)[:n_frames].contiguous()
+        depth = depth.repeat(reps, 1, 1)[:n_frames].contiguous()
+    torch.cuda.synchronize()
+    valid_l0 = float((depth[:-1] != 0).sum().item()) / B            # measured V per pair at level 0
+
+    al = BatchAligner(st["K"], st["depth_scale"], W, H, L, max_pairs=B, device=local_rank,
+                      max_iterations=args.iterations, weighting=args.weighting)
+    counts = [B] * world
+
+    def step():
+        al.ingest_device(gray.data_ptr(), depth.data_ptr(), n_frames)
+        al.solve_enqueue(n_frames)
+        res = al.solve_fetch(n_frames)
+        if world > 1:
+            allgather_poses(pose_records(res["T"], res["iters"], res["err"]), counts, device="cuda")
+        return res
+
+    for _ in range(args.warmup):
+        res = step()
+    if not np.all(np.isfinite(res["xi"])):
+        raise SystemExit("non-finite poses in warm-up")
+
+    def fence():
+        al.ctx.synchronize()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        res = step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+    iters_total = int(res["iters"].sum())
+
+    # --- roofline leg: same steps again with every reduction launch bracketed by HIP events ----------------
+    al.ctx.profile_enable(True)
+    al.ctx.profile_read(reset=True)
+    prof_steps = max(1, min(args.steps, 5))
+    for _ in range(prof_steps):
+        step()
+    launches, ms = al.ctx.profile_read(reset=True)
+    al.ctx.profile_enable(False)
+
+    if rank == 0:
+        P0 = W * H
+        alg_bytes = (2.0 * P0 + 10.0 * valid_l0) * B                  # SURVEY 8d, per level-0 launch
+        layout_bytes = (2.0 * P0 + 5.0 * valid_l0) * B                # this build's packed layout
+        avg_ms = ms[0] / max(launches[0], 1)
+        achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
+        per_level = {str(l): {"launches": int(launches[l]), "avg_us": (1e3 * ms[l] / launches[l]) if launches[l] else None}
+                     for l in range(L)}
+        pairs_per_s = world * B * args.steps / elapsed
+        out = {
+            "metric": "frame-pairs/s (full pyramid GN solve) VGA RGB-D",
+            "value": pairs_per_s,
+            "unit": "frame-pairs/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32 per-pixel math, f64 accumulation/solve",
+            "data": "synthetic",
+            "config": {"workload": "synthetic %dx%d RGB-D stream, %d-level pyramid, %d GN iterations/level, "
+                                   "%d frame pairs per GPU per step (pyramid+Sobel build and device-side GN solve "
+                                   "inside the timed region), weighting=%s" % (W, H, L, args.iterations, B, args.weighting),
+                       "batch_pairs_per_gpu": B, "distinct_frames": int(min(n_distinct, n_frames)),
+                       "gn_iterations_per_pair": iters_total / B,
+                       "gn_iterations_per_s": world * iters_total * args.steps / elapsed,
+                       "parallelism": "1 independent stream per GPU, RCCL all-gather of pose records"},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "k_reduce<V1> level 0 (%dx%d), %d pairs per launch" % (W, H, B),
+                         "avg_launch_us": 1e3 * avg_ms, "launches_timed": int(launches[0]),
+                         "algorithmic_bytes_per_launch": alg_bytes,
+                         "layout_bytes_per_launch": layout_bytes,
+                         "achieved_layout_GBs": layout_bytes / (avg_ms * 1e-3) / 1e9,
+                         "valid_fraction_level0": valid_l0 / P0, "per_level": per_level},
+        }
+        if not args.no_cpu_baseline:
+            cpu_frames = min(args.cpu_pairs + 1, n_frames)
+            st_np = {"gray": gray[:cpu_frames].cpu().numpy(),
+                     "depth": depth[:cpu_frames].cpu().numpy().view(np.uint16),
+                     "K": st["K"], "depth_scale": st["depth_scale"]}
+            out["cpu_baseline"] = cpu_baseline(st_np, L, args.iterations, args.cpu_pairs)
+        print(json.dumps(out))
+    al.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

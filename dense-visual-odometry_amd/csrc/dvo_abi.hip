@@ -52,6 +52,8 @@ struct dvo_ctx {
     float* d_Tinit = nullptr;
     double* d_wparam = nullptr;
     int* d_active = nullptr;
+    int* d_frame_slots = nullptr;
+    int* h_frame_slots = nullptr;
     double* d_partials = nullptr;
     size_t partials_doubles = 0;
     double* d_out = nullptr;
@@ -212,11 +214,11 @@ hipError_t launch_reduce_profiled(dvo_ctx* ctx, const DvoReduceParams& p, int le
         if (ctx->pending.size() > 4096) drain_profile(ctx);
         a = pool_event(ctx);
         b = pool_event(ctx);
-        if (a && b) hipEventRecord(a, ctx->stream);
+        if (a && b) (void)hipEventRecord(a, ctx->stream);
     }
     hipError_t e = dvo_launch_reduce(p, variant, weight_mode, scale_pass, ctx->stream);
     if (ctx->profiling && a && b) {
-        hipEventRecord(b, ctx->stream);
+        (void)hipEventRecord(b, ctx->stream);
         ctx->pending.push_back({a, b, level});
     }
     return e;
@@ -237,7 +239,9 @@ int fill_reduce_params(dvo_ctx* ctx, int level, int n_pairs, int w, int h, DvoRe
     p->wparam = ctx->d_wparam;
     p->active = nullptr;
     p->partials = ctx->d_partials;
-    p->blocks_per_pair = blocks_for(g[level].npix);
+    // more pixels per workgroup on the big levels amortises the 30-term cross-lane reduction
+    p->groups_per_block = (g[level].npix >= 65536) ? 4 : ((g[level].npix >= 16384) ? 2 : 1);
+    p->blocks_per_pair = (g[level].npix + DVO_PX_PER_BLOCK * p->groups_per_block - 1) / (DVO_PX_PER_BLOCK * p->groups_per_block);
     p->n_pairs = n_pairs;
     if ((size_t)n_pairs * p->blocks_per_pair * DVO_STRIDE > ctx->partials_doubles)
         return fail(ctx, DVO_ERR_INVALID_ARG, "internal: partial buffer too small");
@@ -329,6 +333,8 @@ int dvo_create(int device, int max_w, int max_h, int max_levels, int n_slots, in
     CREATE_TRY(hipMalloc((void**)&ctx->d_Tinit, np * 12 * sizeof(float)));
     CREATE_TRY(hipMalloc((void**)&ctx->d_wparam, np * sizeof(double)));
     CREATE_TRY(hipMalloc((void**)&ctx->d_active, np * sizeof(int)));
+    CREATE_TRY(hipMalloc((void**)&ctx->d_frame_slots, (size_t)n_slots * sizeof(int)));
+    CREATE_TRY(hipHostMalloc((void**)&ctx->h_frame_slots, (size_t)n_slots * sizeof(int)));
     ctx->partials_doubles = np * (size_t)blocks_for(max_w * max_h) * DVO_STRIDE;
     CREATE_TRY(hipMalloc((void**)&ctx->d_partials, ctx->partials_doubles * sizeof(double)));
     CREATE_TRY(hipMalloc((void**)&ctx->d_out, np * DVO_STRIDE * sizeof(double)));
@@ -364,9 +370,9 @@ void dvo_destroy(dvo_ctx* ctx)
     if (ctx->tm_a) (void)hipEventDestroy(ctx->tm_a);
     if (ctx->tm_b) (void)hipEventDestroy(ctx->tm_b);
     void* dev[] = {ctx->d_slots, ctx->d_prev, ctx->d_cur, ctx->d_T, ctx->d_Tinit, ctx->d_wparam, ctx->d_active, ctx->d_partials,
-                   ctx->d_out, ctx->d_state, ctx->d_xi, ctx->d_iters, ctx->d_err, ctx->d_stage_img, ctx->d_dense, ctx->d_trace};
+                   ctx->d_out, ctx->d_state, ctx->d_xi, ctx->d_iters, ctx->d_err, ctx->d_stage_img, ctx->d_dense, ctx->d_trace, ctx->d_frame_slots};
     for (void* p : dev) if (p) (void)hipFree(p);
-    void* host[] = {ctx->hs.prev, ctx->hs.cur, ctx->hs.T, ctx->hs.wparam, ctx->hs.out, ctx->hs.xi, ctx->hs.iters, ctx->hs.err};
+    void* host[] = {ctx->hs.prev, ctx->hs.cur, ctx->hs.T, ctx->hs.wparam, ctx->hs.out, ctx->hs.xi, ctx->hs.iters, ctx->hs.err, ctx->h_frame_slots};
     for (void* p : host) if (p) (void)hipHostFree(p);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
@@ -444,6 +450,35 @@ int dvo_upload_frame_device(dvo_ctx* ctx, int slot, const void* d_gray, const vo
     rc = build_pyramid_on_device(ctx, slot, w, h, levels);
     if (rc) return rc;
     ctx->slots[slot].ready = true;
+    return DVO_OK;
+}
+
+int dvo_upload_frames_device(dvo_ctx* ctx, int n_frames, const int* slots, const void* d_gray, const void* d_depth,
+                             int w, int h, int levels)
+{
+    if (!ctx) return DVO_ERR_INVALID_ARG;
+    if (!slots || !d_gray || !d_depth) return fail(ctx, DVO_ERR_INVALID_ARG, "dvo_upload_frames_device: null argument");
+    if (n_frames < 1 || n_frames > ctx->n_slots) return fail(ctx, DVO_ERR_INVALID_ARG, "n_frames %d outside [1,%d]", n_frames, ctx->n_slots);
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    for (int i = 0; i < n_frames; ++i) {
+        for (int j = 0; j < i; ++j)
+            if (slots[j] == slots[i]) return fail(ctx, DVO_ERR_INVALID_ARG, "slot %d listed twice", slots[i]);
+        int rc = prepare_slot(ctx, slots[i], w, h, levels);
+        if (rc) return rc;
+    }
+    DvoBatchIngestParams p;
+    p.slots = ctx->d_slots;
+    p.slot_stride = ctx->slot_stride;
+    p.slot_ids = ctx->d_frame_slots;
+    p.src_gray = static_cast<const uint8_t*>(d_gray);
+    p.src_depth = static_cast<const uint16_t*>(d_depth);
+    p.n_frames = n_frames;
+    p.levels = levels;
+    level_geometry(w, h, levels, p.g, nullptr);
+    memcpy(ctx->h_frame_slots, slots, (size_t)n_frames * sizeof(int));
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->d_frame_slots, ctx->h_frame_slots, (size_t)n_frames * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, dvo_launch_batch_ingest(p, ctx->stream));
+    for (int i = 0; i < n_frames; ++i) ctx->slots[slots[i]].ready = true;
     return DVO_OK;
 }
 

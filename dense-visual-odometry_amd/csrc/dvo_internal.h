@@ -38,6 +38,7 @@ struct DvoReduceParams {
     const int* active;          // [n_pairs] device-mode: 0 => pair skipped at this level; null => all active
     double* partials;           // [n_pairs][blocks_per_pair][DVO_STRIDE]
     int blocks_per_pair;
+    int groups_per_block;       // each workgroup reduces groups_per_block * DVO_PX_PER_BLOCK pixels of one pair
     int n_pairs;
 };
 
@@ -85,12 +86,23 @@ struct DvoSolveParams {
     int trace_stride, trace_cap;
 };
 
+struct DvoBatchIngestParams {
+    uint8_t* slots;
+    size_t slot_stride;
+    const int* slot_ids;         // [n_frames] device
+    const uint8_t* src_gray;     // [n_frames][h][w] device, or null if level 0 is already in the slots
+    const uint16_t* src_depth;   // [n_frames][h][w] device
+    int n_frames, levels;
+    DvoLevelGeom g[8];
+};
+
 // launch wrappers implemented in dvo_kernels.hip -------------------------------------------------
 hipError_t dvo_launch_median_down_u8(const uint8_t* src, int sw, int sh, uint8_t* dst, hipStream_t s);
 hipError_t dvo_launch_median_down_u16(const uint16_t* src, int sw, int sh, uint16_t* dst, hipStream_t s);
 hipError_t dvo_launch_sobel_pack(const uint8_t* gray, int w, int h, uint32_t* packed, int pitch, hipStream_t s);
 hipError_t dvo_launch_bgr_ingest(const uint8_t* bgr, const uint16_t* depth_in, int w, int h, uint8_t* gray,
                                  uint16_t* depth_out, double depth_scale, double max_distance, hipStream_t s);
+hipError_t dvo_launch_batch_ingest(const DvoBatchIngestParams& p, hipStream_t s);
 hipError_t dvo_launch_unpack(const uint32_t* packed, int w, int h, int pitch, int16_t* gx, int16_t* gy, hipStream_t s);
 hipError_t dvo_launch_reduce(const DvoReduceParams& p, int variant, int weight_mode, int scale_pass, hipStream_t s);
 hipError_t dvo_launch_sum_partials(const double* partials, int blocks_per_pair, int n_pairs, double* out, hipStream_t s);

@@ -146,6 +146,94 @@ hipError_t dvo_launch_bgr_ingest(const uint8_t* bgr, const uint16_t* depth_in, i
 }
 
 // ================================================================================================
+// Batched frame ingest: the same K1/K2 arithmetic for n frames per launch (blockIdx.z = frame), so a
+// whole batch of frames costs 3 launches per pyramid level instead of 3 per level per frame.
+// ================================================================================================
+__global__ __launch_bounds__(DVO_BLOCK) void k_batch_copy_level0(const DvoBatchIngestParams p)
+{
+    const int f = blockIdx.z;
+    uint8_t* slot = p.slots + (size_t)p.slot_ids[f] * p.slot_stride;
+    const size_t n = (size_t)p.g[0].npix;
+    const size_t i = ((size_t)blockIdx.x * DVO_BLOCK + threadIdx.x) * 16;
+    if (i >= n) return;
+    const uint8_t* sg = p.src_gray + (size_t)f * n;
+    const uint16_t* sd = p.src_depth + (size_t)f * n;
+    uint8_t* dg = slot + p.g[0].off_gray;
+    uint16_t* dd = reinterpret_cast<uint16_t*>(slot + p.g[0].off_depth);
+    if (i + 16 <= n && (((size_t)f * n) % 16 == 0)) {
+        *reinterpret_cast<uint4*>(dg + i) = *reinterpret_cast<const uint4*>(sg + i);
+        *reinterpret_cast<uint4*>(dd + i) = *reinterpret_cast<const uint4*>(sd + i);
+        *reinterpret_cast<uint4*>(dd + i + 8) = *reinterpret_cast<const uint4*>(sd + i + 8);
+    } else {
+        for (size_t k = i; k < n && k < i + 16; ++k) { dg[k] = sg[k]; dd[k] = sd[k]; }
+    }
+}
+
+template <typename T, bool DEPTH>
+__global__ __launch_bounds__(DVO_BLOCK) void k_batch_median_down(const DvoBatchIngestParams p, int level)
+{
+    const int f = blockIdx.z;
+    uint8_t* slot = p.slots + (size_t)p.slot_ids[f] * p.slot_stride;
+    const DvoLevelGeom& gs = p.g[level - 1];
+    const DvoLevelGeom& gd = p.g[level];
+    const T* src = reinterpret_cast<const T*>(slot + (DEPTH ? gs.off_depth : gs.off_gray));
+    T* dst = reinterpret_cast<T*>(slot + (DEPTH ? gd.off_depth : gd.off_gray));
+    const int sw = gs.w, sh = gs.h, dw = gd.w, dh = gd.h;
+    int x = blockIdx.x * 64 + (threadIdx.x & 63);
+    int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= dw || y >= dh) return;
+    int cx = 2 * x, cy = 2 * y;
+    int xm = max(cx - 1, 0), xp = min(cx + 1, sw - 1);
+    int ym = max(cy - 1, 0), yp = min(cy + 1, sh - 1);
+    const T* r0 = src + (size_t)ym * sw;
+    const T* r1 = src + (size_t)cy * sw;
+    const T* r2 = src + (size_t)yp * sw;
+    dst[(size_t)y * dw + x] = (T)median9(r0[xm], r0[cx], r0[xp], r1[xm], r1[cx], r1[xp], r2[xm], r2[cx], r2[xp]);
+}
+
+__global__ __launch_bounds__(DVO_BLOCK) void k_batch_sobel_pack(const DvoBatchIngestParams p, int level)
+{
+    const int f = blockIdx.z;
+    uint8_t* slot = p.slots + (size_t)p.slot_ids[f] * p.slot_stride;
+    const DvoLevelGeom& g = p.g[level];
+    const uint8_t* gray = slot + g.off_gray;
+    uint32_t* packed = reinterpret_cast<uint32_t*>(slot + g.off_packed);
+    const int w = g.w, h = g.h;
+    int x = blockIdx.x * 64 + (threadIdx.x & 63);
+    int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= w || y >= h) return;
+    int xm = max(x - 1, 0), xp = min(x + 1, w - 1);
+    int ym = max(y - 1, 0), yp = min(y + 1, h - 1);
+    const uint8_t* r0 = gray + (size_t)ym * w;
+    const uint8_t* r1 = gray + (size_t)y * w;
+    const uint8_t* r2 = gray + (size_t)yp * w;
+    int p00 = r0[xm], p01 = r0[x], p02 = r0[xp];
+    int p10 = r1[xm], p11 = r1[x], p12 = r1[xp];
+    int p20 = r2[xm], p21 = r2[x], p22 = r2[xp];
+    int gx = (p02 + 2 * p12 + p22) - (p00 + 2 * p10 + p20);
+    int gy = (p20 + 2 * p21 + p22) - (p00 + 2 * p01 + p02);
+    packed[(size_t)y * g.pitch + x] = (uint32_t)p11 | (((uint32_t)gx & 0xfffu) << 8) | (((uint32_t)gy & 0xfffu) << 20);
+}
+
+hipError_t dvo_launch_batch_ingest(const DvoBatchIngestParams& p, hipStream_t s)
+{
+    const unsigned nf = (unsigned)p.n_frames;
+    if (p.src_gray != nullptr) {
+        dim3 grid((unsigned)((p.g[0].npix + DVO_BLOCK * 16 - 1) / (DVO_BLOCK * 16)), 1, nf);
+        hipLaunchKernelGGL(k_batch_copy_level0, grid, dim3(DVO_BLOCK), 0, s, p);
+    }
+    for (int l = 0; l < p.levels; ++l) {
+        dim3 grid((p.g[l].w + 63) / 64, (p.g[l].h + 3) / 4, nf);
+        if (l > 0) {
+            hipLaunchKernelGGL((k_batch_median_down<uint8_t, false>), grid, dim3(DVO_BLOCK), 0, s, p, l);
+            hipLaunchKernelGGL((k_batch_median_down<uint16_t, true>), grid, dim3(DVO_BLOCK), 0, s, p, l);
+        }
+        hipLaunchKernelGGL(k_batch_sobel_pack, grid, dim3(DVO_BLOCK), 0, s, p, l);
+    }
+    return hipGetLastError();
+}
+
+// ================================================================================================
 // the per-pixel pipeline shared by K3 and K5
 // ================================================================================================
 struct PixelOut {
@@ -273,18 +361,26 @@ __global__ __launch_bounds__(DVO_BLOCK) void k_reduce(const DvoReduceParams p)
 #pragma unroll
     for (int i = 0; i < NACC; ++i) acc[i] = 0.0f;
 
-    const int base = blk * DVO_PX_PER_BLOCK + threadIdx.x * DVO_PX_PER_THREAD;
-    if (base < p.g.npix) {
-        // planes are allocated with >= 16 bytes of slack, so the vector loads below never leave the slot
-        const ushort4 d4 = *reinterpret_cast<const ushort4*>(depth_prev + base);
-        const uchar4 i4 = *reinterpret_cast<const uchar4*>(gray_prev + base);
-        const unsigned dd[4] = {d4.x, d4.y, d4.z, d4.w};
-        const unsigned ii[4] = {i4.x, i4.y, i4.z, i4.w};
-        int vy = base / p.g.w;
-        int ux = base - vy * p.g.w;
+    // Pixel -> lane map: a wave owns 256 consecutive pixels per group and lane L takes pixels L, L+64, L+128,
+    // L+192 of it, so every load instruction of the wave (depth, intensity and the two 8-byte tap rows of the
+    // packed plane) covers 64 neighbouring pixels: whole 128-byte lines, no stride.
+    const int lane_ = threadIdx.x & 63, wave_ = threadIdx.x >> 6;
+    for (int grp = 0; grp < p.groups_per_block; ++grp) {
+        const int seg = ((blk * p.groups_per_block + grp) * (DVO_BLOCK / 64) + wave_) * (64 * DVO_PX_PER_THREAD);
+        if (seg >= p.g.npix) break;                                       // wave-uniform
+        unsigned dd[DVO_PX_PER_THREAD], ii[DVO_PX_PER_THREAD];
 #pragma unroll
         for (int j = 0; j < DVO_PX_PER_THREAD; ++j) {
-            if (base + j < p.g.npix && dd[j] != 0u) {                 // mask = depth != 0 (camera_model.py:195)
+            const int idx = seg + j * 64 + lane_;
+            const bool in = idx < p.g.npix;
+            dd[j] = in ? (unsigned)depth_prev[idx] : 0u;
+            ii[j] = in ? (unsigned)gray_prev[idx] : 0u;
+        }
+        int vy = (seg + lane_) / p.g.w;
+        int ux = (seg + lane_) - vy * p.g.w;
+#pragma unroll
+        for (int j = 0; j < DVO_PX_PER_THREAD; ++j) {
+            if (dd[j] != 0u) {                                            // mask = depth != 0 (camera_model.py:195)
                 PixelOut o;
                 dvo_pixel<VARIANT, !SCALE_PASS>(p.g, p.cam, p.depth_scale, T, packed_cur, packed_prev, ux, vy,
                                                 dd[j], ii[j], o);
@@ -314,11 +410,12 @@ __global__ __launch_bounds__(DVO_BLOCK) void k_reduce(const DvoReduceParams p)
                     }
                 }
             }
-            if (++ux == p.g.w) { ux = 0; ++vy; }
+            ux += 64;
+            while (ux >= p.g.w) { ux -= p.g.w; ++vy; }
         }
     }
 
-    // float32 only inside one lane (<= 4 pixels); everything across lanes / waves / workgroups is float64
+    // float32 only inside one lane (<= 4 * groups_per_block pixels); across lanes / waves / workgroups: float64
     __shared__ double lds[DVO_BLOCK / 64][DVO_STRIDE];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll

@@ -41,6 +41,7 @@ SIGNATURES = {
     "dvo_get_level_intrinsics": (C.c_int, [_ctx, C.c_int, _c_float_p]),
     "dvo_upload_frame": (C.c_int, [_ctx, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int]),
     "dvo_upload_frame_device": (C.c_int, [_ctx, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int]),
+    "dvo_upload_frames_device": (C.c_int, [_ctx, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int]),
     "dvo_upload_frame_bgr": (C.c_int, [_ctx, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_double]),
     "dvo_download_level": (C.c_int, [_ctx, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "dvo_slot_info": (C.c_int, [_ctx, C.c_int, _c_int_p, _c_int_p, _c_int_p]),
@@ -176,6 +177,12 @@ class HipContext:
     def upload_frame_device(self, slot: int, d_gray_ptr: int, d_depth_ptr: int, w: int, h: int, levels: int):
         self._check(self._lib.dvo_upload_frame_device(self._h, slot, C.c_void_p(d_gray_ptr), C.c_void_p(d_depth_ptr),
                                                       w, h, levels))
+
+    def upload_frames_device(self, slots, d_gray_ptr: int, d_depth_ptr: int, w: int, h: int, levels: int):
+        """n frames from contiguous [n][h][w] device arrays (u8 gray, u16 depth) into `slots` (async)."""
+        sl = _as(slots, np.int32)
+        self._check(self._lib.dvo_upload_frames_device(self._h, sl.shape[0], _ptr(sl), C.c_void_p(d_gray_ptr),
+                                                       C.c_void_p(d_depth_ptr), w, h, levels))
 
     def upload_frame_bgr(self, slot: int, bgr: np.ndarray, depth: np.ndarray, levels: int, max_distance: float):
         c = _as(bgr, np.uint8)

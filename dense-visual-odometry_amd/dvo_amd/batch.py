@@ -1,0 +1,154 @@
+"""Batched / sharded front end of the HIP core: many frame pairs per launch, one process per GPU.
+
+With the reference's defaults (`init_guess = identity`, core/base_dense_visual_odometry.py:56, and
+`sigma=None`, base_robust_dvo.py:36) the transform of frame pair (t-1, t) depends on those two frames
+only, so the pairs of a sequence — and separate sequences — are independent units of work
+(SURVEY 8e).  `BatchAligner` keeps a window of frames resident on one GPU and aligns all its
+consecutive pairs in one device-side Gauss-Newton solve; `shard_pairs` / `allgather_poses` split a
+sequence over ranks and gather the per-pair pose records (16 floats each) with one RCCL all-gather;
+`compose_trajectory` is the sequential pose chaining `pose_t = pose_{t-1} * T_t^-1` (:79) on the host.
+"""
+from __future__ import annotations
+
+from typing import Optional, Sequence, Tuple
+
+import numpy as np
+
+from . import _cabi
+
+_WEIGHTS = {"none": _cabi.WEIGHT_NONE, "student_t_reference": _cabi.WEIGHT_STUDENT_T, "huber": _cabi.WEIGHT_HUBER}
+
+
+class BatchAligner:
+    """Aligns up to `max_pairs` consecutive frame pairs per call on one GPU."""
+
+    def __init__(self, K: np.ndarray, depth_scale: float, width: int = 640, height: int = 480, levels: int = 4,
+                 max_pairs: int = 64, device: int = 0, max_iterations: int = 10, tolerance: float = 1e-6,
+                 max_increased_steps_allowed: int = 0, weighting: str = "none", huber_k: float = 1.345,
+                 approximate_image2_gradient: bool = False):
+        if weighting not in _WEIGHTS:
+            raise ValueError("weighting must be one of {}".format(sorted(_WEIGHTS)))
+        self.width, self.height, self.levels, self.max_pairs = width, height, levels, max_pairs
+        self.max_iterations, self.tolerance = max_iterations, tolerance
+        self.max_increased = max_increased_steps_allowed
+        self.weight_mode, self.huber_k = _WEIGHTS[weighting], huber_k
+        self.variant = _cabi.VARIANT_V2 if approximate_image2_gradient else _cabi.VARIANT_V1
+        self.ctx = _cabi.HipContext(device=device, max_w=width, max_h=height, max_levels=levels,
+                                    n_slots=max_pairs + 1, max_pairs=max_pairs)
+        K = np.asarray(K, dtype=np.float32)
+        self.ctx.set_camera(K[0, 0], K[1, 1], K[0, 2], K[1, 2], K[0, 1], depth_scale)
+        self._slots = np.arange(max_pairs + 1, dtype=np.int32)
+
+    def close(self):
+        self.ctx.close()
+
+    # -- frames already resident in HBM (torch tensors / raw device pointers) ---------------------------
+    def ingest_device(self, d_gray_ptr: int, d_depth_ptr: int, n_frames: int):
+        """n_frames contiguous [n][h][w] images (u8 gray, u16 depth) -> slots 0..n-1: pyramids + packed
+        Sobel planes built on the device (async)."""
+        if not (2 <= n_frames <= self.max_pairs + 1):
+            raise ValueError("n_frames must be in [2, {}]".format(self.max_pairs + 1))
+        self.ctx.upload_frames_device(self._slots[:n_frames], d_gray_ptr, d_depth_ptr, self.width, self.height,
+                                      self.levels)
+
+    def ingest_host(self, gray: np.ndarray, depth: np.ndarray):
+        n = gray.shape[0]
+        if not (2 <= n <= self.max_pairs + 1):
+            raise ValueError("n_frames must be in [2, {}]".format(self.max_pairs + 1))
+        for i in range(n):
+            self.ctx.upload_frame(int(self._slots[i]), gray[i], depth[i], self.levels)
+
+    def solve_enqueue(self, n_frames: int, T_init: Optional[np.ndarray] = None):
+        prev = self._slots[:n_frames - 1]
+        self.ctx.solve_batch_enqueue(prev, prev + 1, self.levels, self.max_iterations, self.tolerance,
+                                     self.max_increased, self.variant, self.weight_mode, self.huber_k, T_init)
+
+    def solve_fetch(self, n_frames: int):
+        return self.ctx.solve_batch_fetch(n_frames - 1)
+
+    def align_device(self, d_gray_ptr: int, d_depth_ptr: int, n_frames: int):
+        """ingest + solve of the n_frames-1 consecutive pairs. -> dict(T, xi, iters, err)."""
+        self.ingest_device(d_gray_ptr, d_depth_ptr, n_frames)
+        self.solve_enqueue(n_frames)
+        return self.solve_fetch(n_frames)
+
+    def align_host(self, gray: np.ndarray, depth: np.ndarray):
+        self.ingest_host(gray, depth)
+        self.solve_enqueue(gray.shape[0])
+        return self.solve_fetch(gray.shape[0])
+
+
+# -- sharding over GPUs ------------------------------------------------------------------------------
+def shard_pairs(n_pairs: int, rank: int, world_size: int) -> Tuple[int, int]:
+    """Contiguous range [lo, hi) of pair indices owned by `rank` (pair i = frames (i, i+1); a rank needs
+    frames lo..hi, i.e. one boundary frame is duplicated between neighbouring ranks)."""
+    if world_size < 1 or not (0 <= rank < world_size):
+        raise ValueError("bad rank/world_size")
+    base, rem = divmod(n_pairs, world_size)
+    lo = rank * base + min(rank, rem)
+    hi = lo + base + (1 if rank < rem else 0)
+    return lo, hi
+
+
+def pose_records(T: np.ndarray, iters: Optional[np.ndarray] = None, err: Optional[np.ndarray] = None) -> np.ndarray:
+    """(n,3,4) transforms -> (n,16) float32 records: 12 floats [R|t], iterations, final error, 2 reserved."""
+    n = T.shape[0]
+    rec = np.zeros((n, 16), dtype=np.float32)
+    rec[:, :12] = np.asarray(T, dtype=np.float32).reshape(n, 12)
+    if iters is not None:
+        rec[:, 12] = iters
+    if err is not None:
+        rec[:, 13] = err
+    return rec
+
+
+def allgather_poses(local_records: np.ndarray, counts: Sequence[int], device=None) -> np.ndarray:
+    """All-gather of the per-pair pose records over the default process group (RCCL over xGMI when the
+    backend is "nccl" on ROCm; gloo on CPU in the tests).  `counts[r]` = records owned by rank r; ranks may
+    own different counts, so records are padded to max(counts).  64 B per pair: latency-bound."""
+    import torch
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()):
+        return np.asarray(local_records, dtype=np.float32)
+    world = dist.get_world_size()
+    assert len(counts) == world and local_records.shape[0] == counts[dist.get_rank()]
+    m = max(counts)
+    dev = device if device is not None else ("cuda" if dist.get_backend() == "nccl" else "cpu")
+    buf = torch.zeros((m, 16), dtype=torch.float32, device=dev)
+    if local_records.shape[0]:
+        buf[:local_records.shape[0]] = torch.from_numpy(np.ascontiguousarray(local_records, dtype=np.float32)).to(dev)
+    parts = [torch.empty((m, 16), dtype=torch.float32, device=dev) for _ in range(world)]
+    dist.all_gather(parts, buf)
+    host = torch.stack(parts).cpu().numpy()
+    return np.concatenate([host[r, :counts[r]] for r in range(world)], axis=0)
+
+
+def compose_trajectory(T_rel: np.ndarray, init_pose: Optional[np.ndarray] = None) -> np.ndarray:
+    """Sequential prefix composition pose_t = pose_{t-1} @ inv(T_t) in float64
+    (core/base_dense_visual_odometry.py:79).  T_rel: (n,3,4) or (n,16) records. -> (n+1,4,4)."""
+    T_rel = np.asarray(T_rel, dtype=np.float64)
+    if T_rel.ndim == 2:
+        T_rel = T_rel[:, :12].reshape(-1, 3, 4)
+    n = T_rel.shape[0]
+    poses = np.empty((n + 1, 4, 4), dtype=np.float64)
+    poses[0] = np.eye(4) if init_pose is None else np.asarray(init_pose, dtype=np.float64)
+    for i in range(n):
+        R, t = T_rel[i, :, :3], T_rel[i, :, 3]
+        Tinv = np.eye(4)
+        Tinv[:3, :3] = R.T
+        Tinv[:3, 3] = -R.T @ t
+        poses[i + 1] = poses[i] @ Tinv
+    return poses
+
+
+def absolute_trajectory_error(est_T_wc: np.ndarray, gt_T_wc: np.ndarray) -> float:
+    """TUM-style ATE RMSE (m): rigid (Horn / Kabsch) alignment of the estimated camera positions onto the
+    ground truth, then RMSE of the position residuals."""
+    P = np.asarray(est_T_wc)[:, :3, 3]
+    Q = np.asarray(gt_T_wc)[:, :3, 3]
+    mp, mq = P.mean(axis=0), Q.mean(axis=0)
+    U, _, Vt = np.linalg.svd((Q - mq).T @ (P - mp))
+    D = np.diag([1.0, 1.0, np.sign(np.linalg.det(U @ Vt))])
+    R = U @ D @ Vt
+    res = (Q - mq) - (P - mp) @ R.T
+    return float(np.sqrt(np.mean(np.sum(res * res, axis=1))))

@@ -100,6 +100,10 @@ int dvo_get_level_intrinsics(const dvo_ctx* ctx, int level, float* k3x4);
 int dvo_upload_frame(dvo_ctx* ctx, int slot, const uint8_t* gray, const uint16_t* depth, int w, int h, int levels);
 /* Same, but gray/depth are DEVICE pointers already resident in HBM (async on the ctx stream). */
 int dvo_upload_frame_device(dvo_ctx* ctx, int slot, const void* d_gray, const void* d_depth, int w, int h, int levels);
+/* Batched form: n_frames images, contiguous [n][h][w] DEVICE arrays, into the listed (distinct) slots; three
+ * launches per pyramid level for the whole batch (async on the ctx stream). */
+int dvo_upload_frames_device(dvo_ctx* ctx, int n_frames, const int* slots, const void* d_gray, const void* d_depth,
+                             int w, int h, int levels);
 /* Colour ingest: BGR u8 [h][w][3] -> gray (OpenCV 8-bit fixed point) and depth clamp
  * depth*depth_scale > max_distance -> 0, on device (core/base_dense_visual_odometry.py:58-59). */
 int dvo_upload_frame_bgr(dvo_ctx* ctx, int slot, const uint8_t* bgr, const uint16_t* depth, int w, int h, int levels,

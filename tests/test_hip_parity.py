@@ -196,7 +196,7 @@ def test_normal_equations_vs_oracle_random_poses(hip, frames, pyramids):
         assert n == no
         assert _rel(H, Ho) < 1e-6 and _rel(b, bo) < 5e-6 and abs(swr2 - so) < 1e-6 * so
         assert _rel(_solve(H, b), O.solve_increment(Ho, bo)) < 1e-5
-        assert swr2 == sr2
+        assert abs(swr2 - sr2) <= 1e-8 * sr2
 
 
 def test_batched_call_equals_single_calls_bitwise(hip, golden_dir):
@@ -287,7 +287,7 @@ def test_single_level_to_convergence_host(frames, golden_dir):
     np.testing.assert_allclose(tf.log().reshape(6), g["final_xi"], rtol=0, atol=5e-7)
 
 
-def test_device_solve_batch_nine_pairs(hip, frames, golden_dir):
+def test_device_solve_batch_nine_pairs(hip, frames, pyramids, golden_dir):
     """dvo_solve_batch: nine pairs in one batch, stop rules per pair on the device (pair 7 stops early)."""
     ctx, cabi = hip
     g = np.load(golden_dir / "pairs_l4.npz")
@@ -297,14 +297,25 @@ def test_device_solve_batch_nine_pairs(hip, frames, golden_dir):
     for k in range(9):
         assert res["iters"][k] == int((g["pair"] == k).sum())
         np.testing.assert_allclose(res["xi"][k], g["final_xi"][k], rtol=0, atol=5e-7)
-        np.testing.assert_allclose(res["T"][k], g["final_T"][k][:3], rtol=0, atol=5e-7)
+        np.testing.assert_allclose(res["T"][k], g["final_T"][k][:3], rtol=0, atol=2e-6)   # golden R carries the float32 rounding of So3.exp
     # per-iteration trace: increments of the free-running device loop vs the reference run's
     tr = ctx.trace_read(9)
     for k in range(9):
         sel = np.flatnonzero(g["pair"] == k)
         for j, i in enumerate(sel):
             assert int(round(tr[k, j, 28])) == int(g["n"][i])
-            assert _rel(tr[k, j, 32:38], g["inc64"][i]) < 2e-4      # poses drift by ~1e-8 between the two runs
+            # free-running: the two runs' poses drift apart by ~1e-8, which is ~1e-4 of a late (small) increment
+            assert np.abs(tr[k, j, 32:38] - g["inc64"][i]).max() < 5e-8
+    # teacher-forced: the oracle evaluated at exactly the pose the device used for that iteration
+    for k in (0, 7):
+        sel = np.flatnonzero(g["pair"] == k)
+        for j, i in enumerate(sel):
+            T = np.eye(4, dtype=np.float32)
+            T[:3, :] = tr[k, j, 38:50].reshape(3, 4).astype(np.float32)
+            r, J, _, _ = O.residuals_and_jacobian(_level(frames, pyramids, k, int(g["level"][i])), T)
+            Ho, bo, so, no = O.normal_equations(r, J)
+            assert no == int(round(tr[k, j, 28]))
+            assert _rel(tr[k, j, 32:38], O.solve_increment(Ho, bo)) < 1e-5
     ctx.trace_enable(0)
 
 
@@ -461,7 +472,9 @@ def test_full_size_1280x960_properties():
             d = ctx.download_level(0, lvl, want=("depth",))["depth"]
             r, J, valid, uv, _ = ctx.residuals_jacobian(lvl, 0, 1, I[0])
             assert n == int(valid.sum()) <= int((d != 0).sum())
-            assert swr2 < 1e-6 * max(n, 1) and np.abs(b).max() <= 1e-6 * np.sqrt(np.diag(H)).max() * max(n, 1) ** 0.5
+            # (coordinates round to ~1e-4 px at the identity, so residuals are tiny, not exactly zero)
+            assert swr2 < 1e-6 * max(n, 1)
+            assert np.all(np.abs(b) <= np.sqrt(np.diag(H) * swr2) * (1 + 1e-9))       # Cauchy-Schwarz
             # (b) the fused reduction equals the float64 sum of the dense kernel's rows
             J64 = J[valid].astype(np.float64)
             assert _rel(H, J64.T @ J64) < 1e-6
@@ -472,7 +485,8 @@ def test_full_size_1280x960_properties():
         r0 = ctx.normal_equations(0, [0], [1], T)[0]
         rt = ctx.normal_equations(0, [0], [1], T, _cabi.VARIANT_V1, _cabi.WEIGHT_STUDENT_T, [0.0])[0]
         rh = ctx.normal_equations(0, [0], [1], T, _cabi.VARIANT_V1, _cabi.WEIGHT_HUBER, [1e30])[0]
-        np.testing.assert_allclose(rt[:28], 1.2 * r0[:28], rtol=1e-6)
+        assert _rel(rt[:21], 1.2 * r0[:21]) < 1e-6 and _rel(rt[21:27], 1.2 * r0[21:27]) < 1e-5
+        assert abs(rt[27] - 1.2 * r0[27]) < 1e-6 * rt[27] and rt[28] == r0[28]
         np.testing.assert_allclose(rh[:28], r0[:28], rtol=1e-12)
         # (e) a solve from a perturbed start on identical frames walks back towards the identity
         res = ctx.solve_batch([0], [1], levels=levels, max_iterations=10, T_init=T)
