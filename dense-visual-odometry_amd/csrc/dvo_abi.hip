@@ -239,8 +239,22 @@ int fill_reduce_params(dvo_ctx* ctx, int level, int n_pairs, int w, int h, DvoRe
     p->wparam = ctx->d_wparam;
     p->active = nullptr;
     p->partials = ctx->d_partials;
+    {
+        const char* e = getenv("DVO_XCD_REMAP");
+        p->xcd_remap = (e && e[0] == '1') ? 1 : 0;   // measured slower on MI355X, off by default
+    }
     // more pixels per workgroup on the big levels amortises the 30-term cross-lane reduction
-    p->groups_per_block = (g[level].npix >= 65536) ? 4 : ((g[level].npix >= 16384) ? 2 : 1);
+    // groups so that the launch still has a few thousand workgroups: (pixels of the batch / 1024) / ~4096
+    {
+        const long long total_groups = (long long)n_pairs * ((g[level].npix + DVO_PX_PER_BLOCK - 1) / DVO_PX_PER_BLOCK);
+        int gmax = 16;
+        const char* e = getenv("DVO_MAX_GROUPS");
+        if (e && atoi(e) > 0) gmax = atoi(e);
+        int gp = (int)(total_groups / 4096);
+        if (gp < 1) gp = 1;
+        if (gp > gmax) gp = gmax;
+        p->groups_per_block = gp;
+    }
     p->blocks_per_pair = (g[level].npix + DVO_PX_PER_BLOCK * p->groups_per_block - 1) / (DVO_PX_PER_BLOCK * p->groups_per_block);
     p->n_pairs = n_pairs;
     if ((size_t)n_pairs * p->blocks_per_pair * DVO_STRIDE > ctx->partials_doubles)

@@ -7,7 +7,9 @@
 #include <stddef.h>
 
 #define DVO_BLOCK 256          // 4 wave64 per workgroup
-#define DVO_PX_PER_THREAD 4    // horizontally adjacent pixels per lane (ushort4 / uchar4 loads)
+#ifndef DVO_PX_PER_THREAD
+#define DVO_PX_PER_THREAD 4    // pixels per lane per group (lane L takes pixels L, L+64, ... of the wave segment)
+#endif
 #define DVO_PX_PER_BLOCK (DVO_BLOCK * DVO_PX_PER_THREAD)
 #define DVO_NACC 30            // 21 H + 6 J^T W r + sum w r^2 + N + sum r^2
 #define DVO_STRIDE 32          // doubles per normal-equation record (== DVO_NE_STRIDE)
@@ -38,6 +40,7 @@ struct DvoReduceParams {
     const int* active;          // [n_pairs] device-mode: 0 => pair skipped at this level; null => all active
     double* partials;           // [n_pairs][blocks_per_pair][DVO_STRIDE]
     int blocks_per_pair;
+    int xcd_remap;              // 1: XCD-aware logical block order
     int groups_per_block;       // each workgroup reduces groups_per_block * DVO_PX_PER_BLOCK pixels of one pair
     int n_pairs;
 };

@@ -239,9 +239,18 @@ hipError_t dvo_launch_batch_ingest(const DvoBatchIngestParams& p, hipStream_t s)
 struct PixelOut {
     float r;
     float J[6];
-    float uw, vw;
-    bool valid;
 };
+
+// Phase A of a pixel: geometry up to the in-bounds decision and the tap address (no dependent loads).
+struct PixelGeo {
+    float x, y, z;       // back-projected point (un-warped)
+    float uw, vw;        // warped pixel coordinates
+    int off;             // offset of tap (y0, x0) in the packed plane (0 when !ok, so the load is harmless)
+    bool ok;             // depth != 0 && warped point inside the closed image rectangle
+};
+
+struct __attribute__((packed, aligned(4))) u32x2_a4 { uint32_t a, b; };
+struct PixelTaps { u32x2_a4 t0, t1; uint32_t own; };   // (y0,x0)(y0,x1) / (y1,x0)(y1,x1) / prev-frame pixel (V2)
 
 __device__ __forceinline__ float fast_rcp(float z)
 {
@@ -258,14 +267,8 @@ __device__ __forceinline__ void unpack_tap(uint32_t p, float& I, float& gx, floa
     gy = (float)(((int32_t)p) >> 20);
 }
 
-struct __attribute__((packed, aligned(4))) u32x2_a4 { uint32_t a, b; };
-
-// VARIANT 0 (V1): gradient of I2 sampled at the warped point; 1 (V2): Sobel gradient of I1 at the pixel.
-template <int VARIANT, bool NEED_J>
-__device__ __forceinline__ void dvo_pixel(const DvoLevelGeom& g, const DvoLevelCam& cam, double depth_scale,
-                                          const float* __restrict__ T, const uint32_t* __restrict__ cur,
-                                          const uint32_t* __restrict__ prev_packed, int ux, int vy, unsigned d,
-                                          unsigned i1, PixelOut& o)
+__device__ __forceinline__ void dvo_geo(const DvoLevelGeom& g, const DvoLevelCam& cam, double depth_scale,
+                                        const float* __restrict__ T, int ux, int vy, unsigned d, PixelGeo& o)
 {
     // --- deproject (camera_model.py:195-221) -------------------------------------------------------
     const float z = (float)((double)d * depth_scale);
@@ -282,26 +285,36 @@ __device__ __forceinline__ void dvo_pixel(const DvoLevelGeom& g, const DvoLevelC
     const float vn = (cam.fy * yp) + (cam.cy * zp);
     const float uw = un / zp;      // IEEE division (hipcc default: correctly rounded)
     const float vw = vn / zp;
-    o.uw = uw;
-    o.vw = vw;
     // closed-boundary rule: valid <=> 0 <= x <= W-1 and 0 <= y <= H-1 ; NaN compares false
-    const bool ok = (uw >= 0.0f) && (uw <= (float)(g.w - 1)) && (vw >= 0.0f) && (vw <= (float)(g.h - 1));
-    o.valid = ok;
-    if (!ok) return;
-    // --- bilinear taps from the packed plane (cpu_robust...:202-254) ---------------------------------
-    const float x0f = floorf(uw), y0f = floorf(vw);
-    const int x0 = (int)x0f, y0 = (int)y0f;
-    const float ax = uw - x0f, ay = vw - y0f;          // exact
-    const float bx = (x0f + 1.0f) - uw, by = (y0f + 1.0f) - vw;
+    const bool ok = (d != 0u) && (uw >= 0.0f) && (uw <= (float)(g.w - 1)) && (vw >= 0.0f) && (vw <= (float)(g.h - 1));
+    o.x = x; o.y = y; o.z = z; o.uw = uw; o.vw = vw; o.ok = ok;
+    o.off = ok ? ((int)floorf(vw) * g.pitch + (int)floorf(uw)) : 0;
+}
+
+__device__ __forceinline__ void dvo_load_taps(const DvoLevelGeom& g, const uint32_t* __restrict__ cur,
+                                              const PixelGeo& q, PixelTaps& t)
+{
+    const uint32_t* row0 = cur + q.off;
+    t.t0 = *reinterpret_cast<const u32x2_a4*>(row0);
+    t.t1 = *reinterpret_cast<const u32x2_a4*>(row0 + g.pitch);
+}
+
+// Phase B: bilinear photometric lookup, residual, 1x6 Jacobian row.
+// VARIANT 0 (V1): gradient of I2 sampled at the warped point; 1 (V2): Sobel gradient of I1 at the pixel.
+template <int VARIANT, bool NEED_J>
+__device__ __forceinline__ void dvo_finish(const DvoLevelCam& cam, const PixelGeo& q, const PixelTaps& t,
+                                           unsigned i1, PixelOut& o)
+{
+    // --- bilinear weights (cpu_robust...:202-254) ------------------------------------------------------
+    const float x0f = floorf(q.uw), y0f = floorf(q.vw);
+    const float ax = q.uw - x0f, ay = q.vw - y0f;          // exact
+    const float bx = (x0f + 1.0f) - q.uw, by = (y0f + 1.0f) - q.vw;
     const float w00 = bx * by, w01 = bx * ay, w10 = ax * by, w11 = ax * ay;
-    const uint32_t* row0 = cur + (size_t)y0 * g.pitch + x0;
-    const u32x2_a4 t0 = *reinterpret_cast<const u32x2_a4*>(row0);             // (y0,x0) (y0,x1)
-    const u32x2_a4 t1 = *reinterpret_cast<const u32x2_a4*>(row0 + g.pitch);   // (y1,x0) (y1,x1)
     float I00, I10, I01, I11, gx00, gx10, gx01, gx11, gy00, gy10, gy01, gy11;
-    unpack_tap(t0.a, I00, gx00, gy00);
-    unpack_tap(t0.b, I10, gx10, gy10);
-    unpack_tap(t1.a, I01, gx01, gy01);
-    unpack_tap(t1.b, I11, gx11, gy11);
+    unpack_tap(t.t0.a, I00, gx00, gy00);
+    unpack_tap(t.t0.b, I10, gx10, gy10);
+    unpack_tap(t.t1.a, I01, gx01, gy01);
+    unpack_tap(t.t1.b, I11, gx11, gy11);
     const float i2 = fmaf(w11, I11, fmaf(w10, I10, fmaf(w01, I01, w00 * I00)));
     o.r = i2 - (float)i1;                                                       // :191-194
     if (!NEED_J) return;
@@ -311,11 +324,11 @@ __device__ __forceinline__ void dvo_pixel(const DvoLevelGeom& g, const DvoLevelC
         gyw = fmaf(w11, gy11, fmaf(w10, gy10, fmaf(w01, gy01, w00 * gy00)));
     } else {
         float Ip;
-        unpack_tap(prev_packed[(size_t)vy * g.pitch + ux], Ip, gxw, gyw);       // :69-75 (Sobel of I1 at the pixel)
+        unpack_tap(t.own, Ip, gxw, gyw);                                        // :69-75 (Sobel of I1 at the pixel)
     }
     // --- J_w at the UN-warped point (utils/jacobian.py:39-42, quirk Q2) ------------------------------
-    const float iz = fast_rcp(z);
-    const float a = x * iz, b = y * iz;
+    const float iz = fast_rcp(q.z);
+    const float a = q.x * iz, b = q.y * iz;
     const float fxg = cam.fx * gxw, fyg = cam.fy * gyw;
     // J = gx * Jw[0,:] + gy * Jw[1,:]   (_fill_jacobian, cpu_robust...:79-90)
     o.J[0] = fxg * iz;
@@ -336,12 +349,23 @@ __device__ __forceinline__ double wave_sum(double v)
     return v;
 }
 
+#ifndef DVO_REDUCE_WAVES_PER_SIMD
+#define DVO_REDUCE_WAVES_PER_SIMD 4
+#endif
 template <int VARIANT, int WMODE, bool SCALE_PASS>
-__global__ __launch_bounds__(DVO_BLOCK) void k_reduce(const DvoReduceParams p)
+__global__ __launch_bounds__(DVO_BLOCK, DVO_REDUCE_WAVES_PER_SIMD) void k_reduce(const DvoReduceParams p)
 {
     constexpr int NACC = SCALE_PASS ? 1 : DVO_NACC;
-    const int pair = blockIdx.x / p.blocks_per_pair;
-    const int blk = blockIdx.x - pair * p.blocks_per_pair;
+    // XCD-aware block order (speed only): workgroups are dealt round-robin to the 8 XCDs, so give XCD k the
+    // k-th contiguous eighth of the logical grid; the workgroups of one frame pair (which share tap rows of the
+    // packed plane) then run behind one L2.  Bijective for any grid size.
+    int lb = blockIdx.x;
+    if (p.xcd_remap) {
+        const int nb = gridDim.x, q8 = nb >> 3, r8 = nb & 7, xcd = lb & 7;
+        lb = ((xcd < r8) ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (lb >> 3);
+    }
+    const int pair = lb / p.blocks_per_pair;
+    const int blk = lb - pair * p.blocks_per_pair;
     if (p.active != nullptr && p.active[pair] == 0) return;        // block-uniform
 
     const uint8_t* prev = p.slots + (size_t)p.prev_slot[pair] * p.slot_stride;
@@ -365,69 +389,126 @@ __global__ __launch_bounds__(DVO_BLOCK) void k_reduce(const DvoReduceParams p)
     // L+192 of it, so every load instruction of the wave (depth, intensity and the two 8-byte tap rows of the
     // packed plane) covers 64 neighbouring pixels: whole 128-byte lines, no stride.
     const int lane_ = threadIdx.x & 63, wave_ = threadIdx.x >> 6;
+    // depth / intensity of the next group are requested one group ahead, so their latency is covered by the
+    // arithmetic of the current group and only the dependent tap gathers are waited for
+    unsigned dn[DVO_PX_PER_THREAD], in_[DVO_PX_PER_THREAD];
+    {
+        const int seg0 = (blk * p.groups_per_block * (DVO_BLOCK / 64) + wave_) * (64 * DVO_PX_PER_THREAD);
+#pragma unroll
+        for (int j = 0; j < DVO_PX_PER_THREAD; ++j) {
+            const int idx = seg0 + j * 64 + lane_;
+            const bool in = idx < p.g.npix;
+            dn[j] = in ? (unsigned)depth_prev[idx] : 0u;
+            in_[j] = in ? (unsigned)gray_prev[idx] : 0u;
+        }
+    }
+    int vy0 = 0, ux0 = 0;       // pixel of this lane at the start of the current group (advanced incrementally)
     for (int grp = 0; grp < p.groups_per_block; ++grp) {
         const int seg = ((blk * p.groups_per_block + grp) * (DVO_BLOCK / 64) + wave_) * (64 * DVO_PX_PER_THREAD);
         if (seg >= p.g.npix) break;                                       // wave-uniform
         unsigned dd[DVO_PX_PER_THREAD], ii[DVO_PX_PER_THREAD];
 #pragma unroll
-        for (int j = 0; j < DVO_PX_PER_THREAD; ++j) {
-            const int idx = seg + j * 64 + lane_;
-            const bool in = idx < p.g.npix;
-            dd[j] = in ? (unsigned)depth_prev[idx] : 0u;
-            ii[j] = in ? (unsigned)gray_prev[idx] : 0u;
-        }
-        int vy = (seg + lane_) / p.g.w;
-        int ux = (seg + lane_) - vy * p.g.w;
+        for (int j = 0; j < DVO_PX_PER_THREAD; ++j) { dd[j] = dn[j]; ii[j] = in_[j]; }
+        if (grp + 1 < p.groups_per_block) {
+            const int segn = seg + (DVO_BLOCK / 64) * (64 * DVO_PX_PER_THREAD);
 #pragma unroll
-        for (int j = 0; j < DVO_PX_PER_THREAD; ++j) {
-            if (dd[j] != 0u) {                                            // mask = depth != 0 (camera_model.py:195)
-                PixelOut o;
-                dvo_pixel<VARIANT, !SCALE_PASS>(p.g, p.cam, p.depth_scale, T, packed_cur, packed_prev, ux, vy,
-                                                dd[j], ii[j], o);
-                if (o.valid) {
-                    const float r = o.r;
-                    const float r2 = r * r;
-                    if (SCALE_PASS) {
-                        // r^2 * (dof+1)/(dof + r^2*lambda), dof = 5 (weighter/t_weighter.py:43-45)
-                        acc[0] += r2 * (6.0f * fast_rcp(fmaf(r2, wpar, 5.0f)));
-                    } else {
-                        float wt = 1.0f;
-                        if (WMODE == 1) wt = 6.0f * fast_rcp(fmaf(r2, wpar, 5.0f));          // t_weighter.py:34
-                        if (WMODE == 2) { const float ar = fabsf(r); wt = (ar <= wpar) ? 1.0f : wpar * fast_rcp(ar); }
-                        float wj[6];
-#pragma unroll
-                        for (int k = 0; k < 6; ++k) wj[k] = (WMODE == 0) ? o.J[k] : wt * o.J[k];
-                        int q = 0;
-#pragma unroll
-                        for (int a = 0; a < 6; ++a)
-#pragma unroll
-                            for (int b = a; b < 6; ++b) { acc[q] = fmaf(wj[a], o.J[b], acc[q]); ++q; }
-#pragma unroll
-                        for (int k = 0; k < 6; ++k) acc[21 + k] = fmaf(wj[k], r, acc[21 + k]);
-                        acc[27] = fmaf((WMODE == 0) ? r : wt * r, r, acc[27]);
-                        acc[28] += 1.0f;
-                        acc[29] += r2;
-                    }
-                }
+            for (int j = 0; j < DVO_PX_PER_THREAD; ++j) {
+                const int idx = segn + j * 64 + lane_;
+                const bool in = idx < p.g.npix;
+                dn[j] = in ? (unsigned)depth_prev[idx] : 0u;
+                in_[j] = in ? (unsigned)gray_prev[idx] : 0u;
             }
+        }
+        if (grp == 0) { vy0 = (seg + lane_) / p.g.w; ux0 = (seg + lane_) - vy0 * p.g.w; }
+        int vy = vy0, ux = ux0;
+        // phase A for all pixels of the lane, then all tap loads back to back (memory-level parallelism: the
+        // dependent gathers of 4 pixels are in flight together), then phase B
+        PixelGeo geo[DVO_PX_PER_THREAD];
+        PixelTaps taps[DVO_PX_PER_THREAD];
+#pragma unroll
+        for (int j = 0; j < DVO_PX_PER_THREAD; ++j) {
+            dvo_geo(p.g, p.cam, p.depth_scale, T, ux, vy, dd[j], geo[j]);
+            dvo_load_taps(p.g, packed_cur, geo[j], taps[j]);
+            if (VARIANT == 1) taps[j].own = geo[j].ok ? packed_prev[(size_t)vy * p.g.pitch + ux] : 0u;
             ux += 64;
             while (ux >= p.g.w) { ux -= p.g.w; ++vy; }
         }
+        ux0 = ux + (DVO_BLOCK / 64 - 1) * (64 * DVO_PX_PER_THREAD);          // same lane, next group of this wave
+        vy0 = vy;
+        while (ux0 >= p.g.w) { ux0 -= p.g.w; ++vy0; }
+#pragma unroll
+        for (int j = 0; j < DVO_PX_PER_THREAD; ++j) {
+            if (geo[j].ok) {                                  // depth != 0 (camera_model.py:195) and in bounds
+                PixelOut o;
+                dvo_finish<VARIANT, !SCALE_PASS>(p.cam, geo[j], taps[j], ii[j], o);
+                const float r = o.r;
+                const float r2 = r * r;
+                if (SCALE_PASS) {
+                    // r^2 * (dof+1)/(dof + r^2*lambda), dof = 5 (weighter/t_weighter.py:43-45)
+                    acc[0] += r2 * (6.0f * fast_rcp(fmaf(r2, wpar, 5.0f)));
+                } else {
+                    float wt = 1.0f;
+                    if (WMODE == 1) wt = 6.0f * fast_rcp(fmaf(r2, wpar, 5.0f));              // t_weighter.py:34
+                    if (WMODE == 2) { const float ar = fabsf(r); wt = (ar <= wpar) ? 1.0f : wpar * fast_rcp(ar); }
+                    float wj[6];
+#pragma unroll
+                    for (int k = 0; k < 6; ++k) wj[k] = (WMODE == 0) ? o.J[k] : wt * o.J[k];
+                    int q = 0;
+#pragma unroll
+                    for (int a = 0; a < 6; ++a)
+#pragma unroll
+                        for (int b = a; b < 6; ++b) { acc[q] = fmaf(wj[a], o.J[b], acc[q]); ++q; }
+#pragma unroll
+                    for (int k = 0; k < 6; ++k) acc[21 + k] = fmaf(wj[k], r, acc[21 + k]);
+                    acc[27] = fmaf((WMODE == 0) ? r : wt * r, r, acc[27]);
+                    acc[28] += 1.0f;
+                    acc[29] += r2;
+                }
+            }
+        }
     }
 
-    // float32 only inside one lane (<= 4 * groups_per_block pixels); across lanes / waves / workgroups: float64
-    __shared__ double lds[DVO_BLOCK / 64][DVO_STRIDE];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // Workgroup reduction.  float32 only inside one lane; everything across lanes / waves / workgroups is float64.
+    // The 30 per-lane sums are transposed through LDS instead of 30 x 6 cross-lane butterflies: every lane stores
+    // its sums ([term][thread], padded so stores and loads are bank-conflict free), then 8 lanes per term each add
+    // 32 of the 256 values in float64 (fixed order => reproducible), and a 3-step shuffle joins the 8 segments.
+    // Two rounds of 15 terms keep the LDS footprint at 15.5 KB per workgroup.
+    if (SCALE_PASS) {
+        __shared__ double lds1[DVO_BLOCK / 64];
+        const double sw = wave_sum((double)acc[0]);
+        if ((threadIdx.x & 63) == 0) lds1[threadIdx.x >> 6] = sw;
+        __syncthreads();
+        if (threadIdx.x < DVO_STRIDE) {
+            double tot = 0.0;
+            if (threadIdx.x == 0) tot = (lds1[0] + lds1[1]) + (lds1[2] + lds1[3]);
+            p.partials[((size_t)pair * p.blocks_per_pair + blk) * DVO_STRIDE + threadIdx.x] = tot;
+        }
+    } else {
+        constexpr int ROW = 8 * 33;                          // 8 segments of 32 values + 1 pad each
+        constexpr int HALF = 15;
+        __shared__ float tbuf[HALF * ROW];
+        const int t = threadIdx.x;
+        const int wpos = (t >> 5) * 33 + (t & 31);
+        const int term = t >> 3, segi = t & 7;
+        double* out = p.partials + ((size_t)pair * p.blocks_per_pair + blk) * DVO_STRIDE;
 #pragma unroll
-    for (int i = 0; i < NACC; ++i) {
-        const double s = wave_sum((double)acc[i]);
-        if (lane == 0) lds[wave][i] = s;
-    }
-    __syncthreads();
-    if (threadIdx.x < DVO_STRIDE) {
-        double s = 0.0;
-        if (threadIdx.x < NACC) s = (lds[0][threadIdx.x] + lds[1][threadIdx.x]) + (lds[2][threadIdx.x] + lds[3][threadIdx.x]);
-        p.partials[((size_t)pair * p.blocks_per_pair + blk) * DVO_STRIDE + threadIdx.x] = s;
+        for (int round = 0; round < 2; ++round) {
+            if (round) __syncthreads();                      // previous round's loads are done
+#pragma unroll
+            for (int i = 0; i < HALF; ++i) tbuf[i * ROW + wpos] = acc[round * HALF + i];
+            __syncthreads();
+            double sgm = 0.0;
+            if (t < HALF * 8) {
+                const float* src = tbuf + term * ROW + segi * 33;
+#pragma unroll 8
+                for (int k = 0; k < 32; ++k) sgm += (double)src[k];
+            }
+            sgm += __shfl_xor(sgm, 1, 64);
+            sgm += __shfl_xor(sgm, 2, 64);
+            sgm += __shfl_xor(sgm, 4, 64);
+            if (t < HALF * 8 && segi == 0) out[round * HALF + term] = sgm;
+        }
+        if (t >= 30 && t < DVO_STRIDE) out[t] = 0.0;
     }
 }
 
@@ -505,29 +586,31 @@ __global__ __launch_bounds__(DVO_BLOCK) void k_dense(const DvoDenseParams p)
     const int vy = idx / p.g.w, ux = idx - vy * p.g.w;
     const unsigned d = depth_prev[idx];
     PixelOut o;
-    o.valid = false;
+    PixelGeo q;
+    q.ok = false;
+    q.uw = q.vw = __builtin_nanf("");
     o.r = 0.0f;
-    o.uw = o.vw = __builtin_nanf("");
 #pragma unroll
     for (int k = 0; k < 6; ++k) o.J[k] = 0.0f;
     if (d != 0u) {
         float T[12];
 #pragma unroll
         for (int i = 0; i < 12; ++i) T[i] = p.T[i];
-        dvo_pixel<VARIANT, true>(p.g, p.cam, p.depth_scale, T, packed_cur, packed_prev, ux, vy, d, gray_prev[idx], o);
-        if (!o.valid) {
-            o.r = 0.0f;
-#pragma unroll
-            for (int k = 0; k < 6; ++k) o.J[k] = 0.0f;
+        dvo_geo(p.g, p.cam, p.depth_scale, T, ux, vy, d, q);
+        if (q.ok) {
+            PixelTaps t;
+            dvo_load_taps(p.g, packed_cur, q, t);
+            t.own = (VARIANT == 1) ? packed_prev[(size_t)vy * p.g.pitch + ux] : 0u;
+            dvo_finish<VARIANT, true>(p.cam, q, t, gray_prev[idx], o);
         }
     }
     if (p.r) p.r[idx] = o.r;
-    if (p.valid) p.valid[idx] = o.valid ? 1 : 0;
+    if (p.valid) p.valid[idx] = q.ok ? 1 : 0;
     if (p.J) {
 #pragma unroll
         for (int k = 0; k < 6; ++k) p.J[(size_t)idx * 6 + k] = o.J[k];
     }
-    if (p.uv) { p.uv[(size_t)idx * 2] = o.uw; p.uv[(size_t)idx * 2 + 1] = o.vw; }
+    if (p.uv) { p.uv[(size_t)idx * 2] = q.uw; p.uv[(size_t)idx * 2 + 1] = q.vw; }
 }
 
 hipError_t dvo_launch_dense(const DvoDenseParams& p, int variant, hipStream_t s)
@@ -647,45 +730,16 @@ __device__ inline void se3_log(const double* q, const double* t, double* xi)
     xi[3] = phi[0]; xi[4] = phi[1]; xi[5] = phi[2];
 }
 
-// Solves H x = b for the symmetric positive semi-definite 6x6 H (upper triangle hu[21], row-major).
-// Fast path: Cholesky.  If a pivot is not safely positive (numerically rank deficient H) falls back to the
-// minimum-norm solution through a cyclic Jacobi eigen-decomposition, which is what LAPACK gelsy
-// (base_robust_dvo.py:196-198) returns for a rank-deficient system.
-__device__ inline void solve6(const double* hu, const double* b, double* x)
+// Minimum-norm solution of a numerically rank-deficient symmetric 6x6 system through a cyclic Jacobi
+// eigen-decomposition (what LAPACK gelsy, base_robust_dvo.py:196-198, returns for a rank-deficient system).
+// Rare path: kept out of line so its runtime-indexed arrays do not push the common path into scratch.
+__device__ __noinline__ void solve6_pinv(const double* hu, const double* b, double dmax, double* x)
 {
-    double A[6][6];
+    double A[6][6], V[6][6];
     {
         int q = 0;
         for (int i = 0; i < 6; ++i) for (int j = i; j < 6; ++j) { A[i][j] = hu[q]; A[j][i] = hu[q]; ++q; }
     }
-    bool finite = true;
-    double dmax = 0.0;
-    for (int i = 0; i < 6; ++i) { dmax = fmax(dmax, fabs(A[i][i])); for (int j = 0; j < 6; ++j) finite = finite && isfinite(A[i][j]); }
-    for (int i = 0; i < 6; ++i) finite = finite && isfinite(b[i]);
-    if (!finite) { for (int i = 0; i < 6; ++i) x[i] = __builtin_nan(""); return; }
-    if (dmax == 0.0) { for (int i = 0; i < 6; ++i) x[i] = 0.0; return; }
-    double L[6][6];
-    bool ok = true;
-    for (int j = 0; j < 6 && ok; ++j) {
-        double d = A[j][j];
-        for (int k = 0; k < j; ++k) d -= L[j][k] * L[j][k];
-        if (!(d > 1e-13 * dmax)) { ok = false; break; }
-        const double lj = sqrt(d);
-        L[j][j] = lj;
-        for (int i = j + 1; i < 6; ++i) {
-            double s = A[i][j];
-            for (int k = 0; k < j; ++k) s -= L[i][k] * L[j][k];
-            L[i][j] = s / lj;
-        }
-    }
-    if (ok) {
-        double y[6];
-        for (int i = 0; i < 6; ++i) { double s = b[i]; for (int k = 0; k < i; ++k) s -= L[i][k] * y[k]; y[i] = s / L[i][i]; }
-        for (int i = 5; i >= 0; --i) { double s = y[i]; for (int k = i + 1; k < 6; ++k) s -= L[k][i] * x[k]; x[i] = s / L[i][i]; }
-        return;
-    }
-    // Jacobi eigen-decomposition A = V diag(e) V^T, pseudo-inverse with relative threshold eps_f64 * e_max
-    double V[6][6];
     for (int i = 0; i < 6; ++i) for (int j = 0; j < 6; ++j) V[i][j] = (i == j) ? 1.0 : 0.0;
     for (int sweep = 0; sweep < 30; ++sweep) {
         double off = 0.0;
@@ -695,10 +749,10 @@ __device__ inline void solve6(const double* hu, const double* b, double* x)
             if (A[p][q] == 0.0) continue;
             const double th = (A[q][q] - A[p][p]) / (2.0 * A[p][q]);
             const double tt = (th >= 0 ? 1.0 : -1.0) / (fabs(th) + sqrt(th * th + 1.0));
-            const double c = 1.0 / sqrt(tt * tt + 1.0), s = tt * c;
-            for (int k = 0; k < 6; ++k) { const double akp = A[k][p], akq = A[k][q]; A[k][p] = c * akp - s * akq; A[k][q] = s * akp + c * akq; }
-            for (int k = 0; k < 6; ++k) { const double apk = A[p][k], aqk = A[q][k]; A[p][k] = c * apk - s * aqk; A[q][k] = s * apk + c * aqk; }
-            for (int k = 0; k < 6; ++k) { const double vkp = V[k][p], vkq = V[k][q]; V[k][p] = c * vkp - s * vkq; V[k][q] = s * vkp + c * vkq; }
+            const double c = 1.0 / sqrt(tt * tt + 1.0), sn = tt * c;
+            for (int k = 0; k < 6; ++k) { const double akp = A[k][p], akq = A[k][q]; A[k][p] = c * akp - sn * akq; A[k][q] = sn * akp + c * akq; }
+            for (int k = 0; k < 6; ++k) { const double apk = A[p][k], aqk = A[q][k]; A[p][k] = c * apk - sn * aqk; A[q][k] = sn * apk + c * aqk; }
+            for (int k = 0; k < 6; ++k) { const double vkp = V[k][p], vkq = V[k][q]; V[k][p] = c * vkp - sn * vkq; V[k][q] = sn * vkp + c * vkq; }
         }
     }
     double emax = 0.0;
@@ -712,6 +766,78 @@ __device__ inline void solve6(const double* hu, const double* b, double* x)
         vb /= e;
         for (int i = 0; i < 6; ++i) x[i] += V[i][k] * vb;
     }
+}
+
+// Solves H x = b for the symmetric positive semi-definite 6x6 H (upper triangle hu[21], row-major).
+// Fast path: fully unrolled Cholesky held in registers; falls back to solve6_pinv when a pivot is not safely
+// positive.
+__device__ __forceinline__ void solve6(const double* hu, const double* b, double* x)
+{
+    double A[6][6];
+    {
+        int q = 0;
+#pragma unroll
+        for (int i = 0; i < 6; ++i)
+#pragma unroll
+            for (int j = i; j < 6; ++j) { A[i][j] = hu[q]; A[j][i] = hu[q]; ++q; }
+    }
+    bool finite = true;
+    double dmax = 0.0;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        dmax = fmax(dmax, fabs(A[i][i]));
+        finite = finite && isfinite(b[i]);
+#pragma unroll
+        for (int j = i; j < 6; ++j) finite = finite && isfinite(A[i][j]);
+    }
+    if (!finite) {
+#pragma unroll
+        for (int i = 0; i < 6; ++i) x[i] = __builtin_nan("");
+        return;
+    }
+    if (dmax == 0.0) {
+#pragma unroll
+        for (int i = 0; i < 6; ++i) x[i] = 0.0;
+        return;
+    }
+    double L[6][6];
+    bool ok = true;
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+        double d = A[j][j];
+#pragma unroll
+        for (int k = 0; k < j; ++k) d -= L[j][k] * L[j][k];
+        ok = ok && (d > 1e-13 * dmax);
+        const double lj = sqrt(ok ? d : 1.0);
+        const double ilj = 1.0 / lj;
+        L[j][j] = lj;
+#pragma unroll
+        for (int i = j + 1; i < 6; ++i) {
+            double sacc = A[i][j];
+#pragma unroll
+            for (int k = 0; k < j; ++k) sacc -= L[i][k] * L[j][k];
+            L[i][j] = sacc * ilj;
+        }
+    }
+    if (ok) {
+        double y[6];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            double sacc = b[i];
+#pragma unroll
+            for (int k = 0; k < i; ++k) sacc -= L[i][k] * y[k];
+            y[i] = sacc / L[i][i];
+        }
+#pragma unroll
+        for (int i = 5; i >= 0; --i) {
+            double sacc = y[i];
+#pragma unroll
+            for (int k = i + 1; k < 6; ++k) sacc -= L[k][i] * x[k];
+            x[i] = sacc / L[i][i];
+        }
+        return;
+    }
+    solve6_pinv(hu, b, dmax, x);
 }
 
 __global__ void k_init_state(DvoPairState* st, float* T, const float* T_init, int n_pairs, double lambda0)

@@ -19,7 +19,10 @@ MAX_LEVELS = 8
 VARIANT_V1, VARIANT_V2, VARIANT_V3 = 0, 1, 2
 WEIGHT_NONE, WEIGHT_STUDENT_T, WEIGHT_HUBER = 0, 1, 2
 
-_LIB_PATH = Path(__file__).resolve().parent / "libdvo_hip.so"
+import os as _os
+
+# DVO_HIP_LIB: alternative build of the same library (kernel-tuning experiments); default = in-tree build
+_LIB_PATH = Path(_os.environ.get("DVO_HIP_LIB") or (Path(__file__).resolve().parent / "libdvo_hip.so"))
 
 # every symbol include/dvo_hip.h declares: name -> (restype, argtypes)
 _c_int_p = C.POINTER(C.c_int)

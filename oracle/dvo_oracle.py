@@ -545,11 +545,11 @@ def gauss_newton(gray_prev, depth_prev, gray_cur, K, depth_scale, levels: int, m
     estimate = init if init is not None else Pose.identity()
     if weighting is None:
         weighting = "student_t_reference" if use_weighter else "none"
+    sigma_prev = None
     for level in range(levels - 1, -1, -1):
         lv = PairLevel(gp[level], dp[level], gc[level], level_intrinsics(K, level), depth_scale)
         err_prev = float(np.finfo("float32").max)
         increased = 0
-        sigma_prev = None
         for i in range(max_iterations):
             T = estimate.matrix()
             r, J, _, _ = residuals_and_jacobian(lv, T, variant)
@@ -557,15 +557,16 @@ def gauss_newton(gray_prev, depth_prev, gray_cur, K, depth_scale, levels: int, m
             if weighting == "student_t_reference":
                 w, _ = student_t_weights(r)
             elif weighting == "huber":
-                r64 = r.astype(np.float64).reshape(-1)
-                sig = math.sqrt(float(np.sum(r64 * r64)) / max(n, 1)) if sigma_prev is None else sigma_prev
-                w = huber_weights(r, huber_k * sig)
+                # build-defined (no reference counterpart): k = huber_k * sigma of the PREVIOUS evaluated
+                # iteration of this pair (carried across levels); the very first iteration is unweighted
+                w = None if sigma_prev is None else huber_weights(np.asarray(r, dtype=np.float32),
+                                                                  float(np.float32(huber_k * sigma_prev)))
             else:
                 w = None
             H, b, s, n = normal_equations(r, J, w, accumulate)
             if weighting == "huber":
-                r64 = r.astype(np.float64).reshape(-1)
-                sigma_prev = math.sqrt(float(np.sum(r64 * r64)) / max(n, 1))
+                r64 = r.astype(np.float32).astype(np.float64).reshape(-1)
+                sigma_prev = math.sqrt(float(np.sum(r64 * r64)) / n) if n else None
             err = float(np.float32(s / n)) if n else float("nan")             # :177 / :184 (float32 mean)
             inc_xi = solve_increment(H, b)
             if record is not None:

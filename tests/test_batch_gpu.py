@@ -1,0 +1,85 @@
+"""BatchAligner / synthetic streams on the GPU: the batched device-side solve against ground truth and
+against the oracle (BASELINE configs 2/3/5 stand-ins).  Run with -m gpu."""
+import numpy as np
+import pytest
+
+import dvo_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def vga_stream():
+    from dvo_amd import synthetic
+    return synthetic.make_stream(9, 640, 480, seed=5, device="cuda")
+
+
+def test_batch_matches_ground_truth_and_oracle(vga_stream):
+    from dvo_amd.batch import BatchAligner, compose_trajectory, absolute_trajectory_error
+    from dvo_amd import synthetic
+    st = vga_stream
+    al = BatchAligner(st["K"], st["depth_scale"], 640, 480, 4, max_pairs=8, max_iterations=10)
+    res = al.align_host(st["gray"], st["depth"])
+    al.close()
+    assert (res["iters"] == 40).all()
+    for k in range(8):
+        gt = synthetic.relative_transform(st["T_wc"][k], st["T_wc"][k + 1])
+        assert np.abs(res["T"][k] - gt[:3]).max() < 2e-3          # converges to the rendered motion
+    # oracle on two of the pairs: same answer to float32-pose accuracy
+    for k in (0, 5):
+        est = O.gauss_newton(st["gray"][k], st["depth"][k], st["gray"][k + 1], st["K"], st["depth_scale"],
+                             levels=4, max_iterations=10)
+        np.testing.assert_allclose(res["xi"][k], est.log(), rtol=0, atol=1e-6)
+    traj = compose_trajectory(res["T"], init_pose=st["T_wc"][0])
+    assert absolute_trajectory_error(traj, st["T_wc"]) < 2e-3      # metres, 8 frames of ~1 cm steps
+
+
+def test_device_ingest_equals_host_ingest(vga_stream):
+    """dvo_upload_frames_device (batched, from HBM) builds bit-identical pyramids to per-frame host uploads."""
+    import torch
+    from dvo_amd.batch import BatchAligner
+    st = vga_stream
+    al = BatchAligner(st["K"], st["depth_scale"], 640, 480, 4, max_pairs=8, max_iterations=10)
+    g = torch.from_numpy(st["gray"]).cuda()
+    d = torch.from_numpy(st["depth"].view(np.int16)).cuda()
+    al.ingest_device(g.data_ptr(), d.data_ptr(), 9)
+    al.ctx.synchronize()
+    gp = O.build_pyramid(st["gray"][4], 4)
+    dp = O.build_pyramid(st["depth"][4], 4)
+    for lvl in range(4):
+        got = al.ctx.download_level(4, lvl)
+        assert np.array_equal(got["gray"], gp[lvl]) and np.array_equal(got["depth"], dp[lvl])
+        gx, gy = O.sobel3(gp[lvl])
+        assert np.array_equal(got["gx"], gx.astype(np.int16)) and np.array_equal(got["gy"], gy.astype(np.int16))
+    al.solve_enqueue(9)
+    res_dev = al.solve_fetch(9)
+    res_host = al.align_host(st["gray"], st["depth"])
+    al.close()
+    assert np.array_equal(res_dev["xi"], res_host["xi"])            # same data, deterministic reduction
+
+
+def test_huber_and_student_t_device_vs_oracle(vga_stream):
+    from dvo_amd.batch import BatchAligner
+    st = vga_stream
+    for weighting, kw in (("huber", dict(weighting="huber")), ("student_t_reference", dict(use_weighter=True))):
+        al = BatchAligner(st["K"], st["depth_scale"], 640, 480, 3, max_pairs=8, max_iterations=6, weighting=weighting)
+        res = al.align_host(st["gray"][:3], st["depth"][:3])
+        al.close()
+        for k in range(2):
+            est = O.gauss_newton(st["gray"][k], st["depth"][k], st["gray"][k + 1], st["K"], st["depth_scale"],
+                                 levels=3, max_iterations=6, **kw)
+            np.testing.assert_allclose(res["xi"][k], est.log(), rtol=0, atol=2e-6)
+
+
+def test_config3_1280x960_five_levels_huber():
+    """BASELINE config 3 shape: 1280x960, 5-level pyramid, Huber weighting — converges to the rendered motion."""
+    from dvo_amd import synthetic
+    from dvo_amd.batch import BatchAligner
+    st = synthetic.make_stream(3, 1280, 960, seed=11, device="cuda")
+    al = BatchAligner(st["K"], st["depth_scale"], 1280, 960, 5, max_pairs=2, max_iterations=10, weighting="huber")
+    res = al.align_host(st["gray"], st["depth"])
+    al.close()
+    for k in range(2):
+        gt = synthetic.relative_transform(st["T_wc"][k], st["T_wc"][k + 1])
+        assert np.abs(res["T"][k] - gt[:3]).max() < 2e-3
+        assert res["iters"][k] > 25

@@ -1,0 +1,101 @@
+"""Multi-rank path on CPU (gloo, world_size 2): pair sharding, pose-record all-gather, pose chaining.
+The GPU ranks use the same code with backend "nccl" (= RCCL over xGMI)."""
+import os
+import socket
+import subprocess
+import sys
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+from dvo_amd.batch import shard_pairs, pose_records, compose_trajectory, absolute_trajectory_error
+
+ROOT = Path(__file__).resolve().parents[1]
+
+
+def test_shard_pairs_partitions_exactly():
+    for n in (0, 1, 7, 8, 9, 100, 797):
+        for world in (1, 2, 3, 8):
+            cover = []
+            for r in range(world):
+                lo, hi = shard_pairs(n, r, world)
+                assert 0 <= lo <= hi <= n
+                cover += list(range(lo, hi))
+            assert cover == list(range(n))
+            sizes = [shard_pairs(n, r, world)[1] - shard_pairs(n, r, world)[0] for r in range(world)]
+            assert max(sizes) - min(sizes) <= 1
+    with pytest.raises(ValueError):
+        shard_pairs(4, 2, 2)
+
+
+def test_compose_trajectory_matches_reference_sequence(golden_dir):
+    """pose_t = pose_{t-1} * T_t^-1 (core/base_dense_visual_odometry.py:79) against the chained reference run."""
+    g = np.load(golden_dir / "sequence.npz")
+    poses = compose_trajectory(g["tf_T"][1:, :3, :], init_pose=g["pose_T"][0].astype(np.float64))
+    np.testing.assert_allclose(poses, g["pose_T"], atol=5e-6)
+    rec = pose_records(g["tf_T"][1:, :3, :], iters=np.full(9, 40), err=np.ones(9))
+    np.testing.assert_allclose(compose_trajectory(rec, init_pose=g["pose_T"][0]), poses, atol=1e-6)
+
+
+def test_ate_is_invariant_to_rigid_motion():
+    rng = np.random.default_rng(0)
+    gt = np.tile(np.eye(4), (20, 1, 1))
+    gt[:, :3, 3] = np.cumsum(rng.normal(0, 0.05, (20, 3)), axis=0)
+    th = 0.7
+    R = np.array([[np.cos(th), -np.sin(th), 0], [np.sin(th), np.cos(th), 0], [0, 0, 1]])
+    est = gt.copy()
+    est[:, :3, 3] = gt[:, :3, 3] @ R.T + np.array([1.0, -2.0, 0.5])
+    assert absolute_trajectory_error(est, gt) < 1e-12
+    est[7, :3, 3] += np.array([0.1, 0, 0])
+    assert 0.005 < absolute_trajectory_error(est, gt) < 0.05
+
+
+_WORKER = r'''
+import os, sys
+import numpy as np
+import torch.distributed as dist
+sys.path.insert(0, os.environ["DVO_PKG_DIR"])
+from dvo_amd.batch import shard_pairs, pose_records, allgather_poses, compose_trajectory
+
+dist.init_process_group(backend="gloo")
+rank, world = dist.get_rank(), dist.get_world_size()
+g = np.load(os.environ["DVO_GOLDEN"])
+T_all = g["tf_T"][1:, :3, :]                       # nine relative transforms of the reference run
+n = T_all.shape[0]
+lo, hi = shard_pairs(n, rank, world)
+counts = [shard_pairs(n, r, world)[1] - shard_pairs(n, r, world)[0] for r in range(world)]
+local = pose_records(T_all[lo:hi], iters=np.arange(lo, hi), err=np.full(hi - lo, float(rank)))
+allrec = allgather_poses(local, counts)
+assert allrec.shape == (n, 16), allrec.shape
+assert np.array_equal(allrec[:, :12].reshape(n, 3, 4), T_all.astype(np.float32))
+assert np.array_equal(allrec[:, 12], np.arange(n, dtype=np.float32))            # order preserved across ranks
+assert np.array_equal(allrec[:, 13], np.repeat(np.arange(world, dtype=np.float32), counts))
+poses = compose_trajectory(allrec, init_pose=g["pose_T"][0].astype(np.float64))
+assert np.abs(poses - g["pose_T"]).max() < 5e-6
+dist.barrier()
+dist.destroy_process_group()
+print("rank %d ok" % rank)
+'''
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_allgather_poses_gloo(tmp_path, golden_dir, world):
+    script = tmp_path / "worker.py"
+    script.write_text(_WORKER)
+    env = dict(os.environ, DVO_PKG_DIR=str(ROOT / "dense-visual-odometry_amd"),
+               DVO_GOLDEN=str(golden_dir / "sequence.npz"), OMP_NUM_THREADS="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), str(script)]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+    for r in range(world):
+        assert "rank %d ok" % r in out.stdout
