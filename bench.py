@@ -34,7 +34,7 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=128, help="frame pairs per GPU per step")
+    ap.add_argument("--batch", type=int, default=256, help="frame pairs per GPU per step")
     ap.add_argument("--width", type=int, default=640)
     ap.add_argument("--height", type=int, default=480)
     ap.add_argument("--levels", type=int, default=4)

@@ -45,6 +45,8 @@ struct dvo_ctx {
     bool have_camera = false;
     float fx = 0, fy = 0, cx = 0, cy = 0, skew = 0;
     double depth_scale = 0;
+    float ds_hi = 0, ds_lo = 0;
+    int z_fast = 0;
     // scratch (device)
     int* d_prev = nullptr;
     int* d_cur = nullptr;
@@ -149,6 +151,8 @@ DvoLevelCam level_camera(const dvo_ctx* c, int level)
     volatile float t = (-se) - k.cx;
     volatile float ic = t / k.fx;
     k.ia = ia; k.ib = ib; k.ic = ic; k.id = id; k.ie = ie;
+    k.ds_hi = c->ds_hi; k.ds_lo = c->ds_lo; k.z_fast = c->z_fast;
+    k.skew0 = (k.s == 0.0f && k.ib == 0.0f) ? 1 : 0;
     return k;
 }
 
@@ -238,6 +242,7 @@ int fill_reduce_params(dvo_ctx* ctx, int level, int n_pairs, int w, int h, DvoRe
     p->T = ctx->d_T;
     p->wparam = ctx->d_wparam;
     p->active = nullptr;
+    p->finest = (level == 0) ? 1 : 0;
     p->partials = ctx->d_partials;
     {
         const char* e = getenv("DVO_XCD_REMAP");
@@ -415,6 +420,20 @@ int dvo_set_camera(dvo_ctx* ctx, float fx, float fy, float cx, float cy, float s
     if (!(fx > 0.f) || !(fy > 0.f) || !(depth_scale >= 0.0) || !std::isfinite(cx) || !std::isfinite(cy) || !std::isfinite(skew))
         return fail(ctx, DVO_ERR_INVALID_ARG, "dvo_set_camera: need fx, fy > 0 and depth_scale >= 0");
     ctx->fx = fx; ctx->fy = fy; ctx->cx = cx; ctx->cy = cy; ctx->skew = skew; ctx->depth_scale = depth_scale;
+    // float32 double-word form of depth_scale; usable in the kernels only if it reproduces the reference's
+    // (float)((double)d * depth_scale) for every 16-bit depth value — checked here, exhaustively.
+    ctx->ds_hi = (float)depth_scale;
+    ctx->ds_lo = (float)(depth_scale - (double)ctx->ds_hi);
+    ctx->z_fast = 1;
+    for (unsigned d = 0; d < 65536u && ctx->z_fast; ++d) {
+        const float ref = (float)((double)d * depth_scale);
+        const float df = (float)d;
+        volatile float ph = df * ctx->ds_hi;
+        const float el = std::fmaf(df, ctx->ds_hi, -ph);
+        volatile float tl = std::fmaf(df, ctx->ds_lo, el);
+        volatile float z = ph + tl;
+        if (!(z == ref)) ctx->z_fast = 0;
+    }
     ctx->have_camera = true;
     return DVO_OK;
 }

@@ -25,6 +25,9 @@ struct DvoLevelGeom {
 struct DvoLevelCam {
     float fx, fy, cx, cy, s;
     float ia, ib, ic, id, ie;   // inv(K) = [[ia ib ic],[0 id ie],[0 0 1]]
+    float ds_hi, ds_lo;         // depth_scale as a float32 double-word (hi + lo)
+    int z_fast;                 // 1: float32 double-word product verified == (float)((double)d * depth_scale) for all d
+    int skew0;                  // 1: skew == 0 (the zero terms of the reference's matrix products are skipped: exact)
 };
 
 struct DvoReduceParams {
@@ -41,6 +44,7 @@ struct DvoReduceParams {
     double* partials;           // [n_pairs][blocks_per_pair][DVO_STRIDE]
     int blocks_per_pair;
     int xcd_remap;              // 1: XCD-aware logical block order
+    int finest;                 // level == 0 (kernel-name tag only)
     int groups_per_block;       // each workgroup reduces groups_per_block * DVO_PX_PER_BLOCK pixels of one pair
     int n_pairs;
 };

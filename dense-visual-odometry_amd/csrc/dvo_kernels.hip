@@ -267,13 +267,32 @@ __device__ __forceinline__ void unpack_tap(uint32_t p, float& I, float& gx, floa
     gy = (float)(((int32_t)p) >> 20);
 }
 
+// z = (float)((double)d * depth_scale) (camera_model.py:200-201).  When the host has verified for all 65536
+// depth values that the float32 double-word product below rounds identically (DvoLevelCam::z_fast), the three
+// slow float64 instructions are replaced by four float32 ones.
+__device__ __forceinline__ float dvo_depth_to_z(unsigned d, double depth_scale, const DvoLevelCam& cam)
+{
+    if (cam.z_fast) {
+        const float df = (float)d;
+        const float ph = df * cam.ds_hi;
+        const float el = fmaf(df, cam.ds_hi, -ph);            // exact rounding error of ph
+        return ph + fmaf(df, cam.ds_lo, el);
+    }
+    return (float)((double)d * depth_scale);
+}
+
 __device__ __forceinline__ void dvo_geo(const DvoLevelGeom& g, const DvoLevelCam& cam, double depth_scale,
                                         const float* __restrict__ T, int ux, int vy, unsigned d, PixelGeo& o)
 {
+    o.ok = false;
+    o.off = 0;
+    o.x = o.y = o.z = 0.0f;
+    o.uw = o.vw = __builtin_nanf("");
+    if (d == 0u) return;                                      // mask = depth != 0 (camera_model.py:195)
     // --- deproject (camera_model.py:195-221) -------------------------------------------------------
-    const float z = (float)((double)d * depth_scale);
+    const float z = dvo_depth_to_z(d, depth_scale, cam);
     const float u = (float)ux, v = (float)vy;
-    const float xn = ((cam.ia * u) + (cam.ib * v)) + cam.ic;
+    const float xn = cam.skew0 ? ((cam.ia * u) + cam.ic) : (((cam.ia * u) + (cam.ib * v)) + cam.ic);   // ib == 0: + 0 is exact
     const float yn = (cam.id * v) + cam.ie;
     const float x = xn * z;
     const float y = yn * z;
@@ -281,12 +300,12 @@ __device__ __forceinline__ void dvo_geo(const DvoLevelGeom& g, const DvoLevelCam
     const float xp = ((T[0] * x + T[1] * y) + T[2] * z) + T[3];
     const float yp = ((T[4] * x + T[5] * y) + T[6] * z) + T[7];
     const float zp = ((T[8] * x + T[9] * y) + T[10] * z) + T[11];
-    const float un = ((cam.fx * xp) + (cam.s * yp)) + (cam.cx * zp);
+    const float un = cam.skew0 ? ((cam.fx * xp) + (cam.cx * zp)) : (((cam.fx * xp) + (cam.s * yp)) + (cam.cx * zp));
     const float vn = (cam.fy * yp) + (cam.cy * zp);
     const float uw = un / zp;      // IEEE division (hipcc default: correctly rounded)
     const float vw = vn / zp;
     // closed-boundary rule: valid <=> 0 <= x <= W-1 and 0 <= y <= H-1 ; NaN compares false
-    const bool ok = (d != 0u) && (uw >= 0.0f) && (uw <= (float)(g.w - 1)) && (vw >= 0.0f) && (vw <= (float)(g.h - 1));
+    const bool ok = (uw >= 0.0f) && (uw <= (float)(g.w - 1)) && (vw >= 0.0f) && (vw <= (float)(g.h - 1));
     o.x = x; o.y = y; o.z = z; o.uw = uw; o.vw = vw; o.ok = ok;
     o.off = ok ? ((int)floorf(vw) * g.pitch + (int)floorf(uw)) : 0;
 }
@@ -308,7 +327,7 @@ __device__ __forceinline__ void dvo_finish(const DvoLevelCam& cam, const PixelGe
     // --- bilinear weights (cpu_robust...:202-254) ------------------------------------------------------
     const float x0f = floorf(q.uw), y0f = floorf(q.vw);
     const float ax = q.uw - x0f, ay = q.vw - y0f;          // exact
-    const float bx = (x0f + 1.0f) - q.uw, by = (y0f + 1.0f) - q.vw;
+    const float bx = 1.0f - ax, by = 1.0f - ay;            // == (x0+1) - x up to one rounding when x < 1
     const float w00 = bx * by, w01 = bx * ay, w10 = ax * by, w11 = ax * ay;
     float I00, I10, I01, I11, gx00, gx10, gx01, gx11, gy00, gy10, gy01, gy11;
     unpack_tap(t.t0.a, I00, gx00, gy00);
@@ -331,12 +350,13 @@ __device__ __forceinline__ void dvo_finish(const DvoLevelCam& cam, const PixelGe
     const float a = q.x * iz, b = q.y * iz;
     const float fxg = cam.fx * gxw, fyg = cam.fy * gyw;
     // J = gx * Jw[0,:] + gy * Jw[1,:]   (_fill_jacobian, cpu_robust...:79-90)
+    const float ab = a * b;
     o.J[0] = fxg * iz;
     o.J[1] = fyg * iz;
-    o.J[2] = -(fxg * a + fyg * b) * iz;
-    o.J[3] = -(fxg * (a * b) + fyg * fmaf(b, b, 1.0f));
-    o.J[4] = fxg * fmaf(a, a, 1.0f) + fyg * (a * b);
-    o.J[5] = fyg * a - fxg * b;
+    o.J[2] = -fmaf(fxg, a, fyg * b) * iz;
+    o.J[3] = -fmaf(fxg, ab, fyg * fmaf(b, b, 1.0f));
+    o.J[4] = fmaf(fxg, fmaf(a, a, 1.0f), fyg * ab);
+    o.J[5] = fmaf(fyg, a, -(fxg * b));
 }
 
 // ================================================================================================
@@ -352,7 +372,8 @@ __device__ __forceinline__ double wave_sum(double v)
 #ifndef DVO_REDUCE_WAVES_PER_SIMD
 #define DVO_REDUCE_WAVES_PER_SIMD 4
 #endif
-template <int VARIANT, int WMODE, bool SCALE_PASS>
+// FINEST only tags the instantiation (level 0 gets its own kernel name in rocprofv3 --stats); codegen is identical.
+template <int VARIANT, int WMODE, bool SCALE_PASS, bool FINEST>
 __global__ __launch_bounds__(DVO_BLOCK, DVO_REDUCE_WAVES_PER_SIMD) void k_reduce(const DvoReduceParams p)
 {
     constexpr int NACC = SCALE_PASS ? 1 : DVO_NACC;
@@ -462,12 +483,13 @@ __global__ __launch_bounds__(DVO_BLOCK, DVO_REDUCE_WAVES_PER_SIMD) void k_reduce
                     for (int k = 0; k < 6; ++k) acc[21 + k] = fmaf(wj[k], r, acc[21 + k]);
                     acc[27] = fmaf((WMODE == 0) ? r : wt * r, r, acc[27]);
                     acc[28] += 1.0f;
-                    acc[29] += r2;
+                    if (WMODE != 0) acc[29] += r2;             // WMODE 0: copied from acc[27] after the loop
                 }
             }
         }
     }
 
+    if (!SCALE_PASS && WMODE == 0) acc[NACC - 1] = acc[NACC - 3];     // sum r^2 == sum w r^2 when w == 1
     // Workgroup reduction.  float32 only inside one lane; everything across lanes / waves / workgroups is float64.
     // The 30 per-lane sums are transposed through LDS instead of 30 x 6 cross-lane butterflies: every lane stores
     // its sums ([term][thread], padded so stores and loads are bank-conflict free), then 8 lanes per term each add
@@ -512,26 +534,30 @@ __global__ __launch_bounds__(DVO_BLOCK, DVO_REDUCE_WAVES_PER_SIMD) void k_reduce
     }
 }
 
-template <int VARIANT>
+template <int VARIANT, bool FINEST>
 static hipError_t launch_reduce_v(const DvoReduceParams& p, int weight_mode, int scale_pass, hipStream_t s)
 {
     dim3 grid((unsigned)(p.n_pairs * p.blocks_per_pair)), block(DVO_BLOCK);
     if (scale_pass) {
-        hipLaunchKernelGGL((k_reduce<VARIANT, 1, true>), grid, block, 0, s, p);
+        hipLaunchKernelGGL((k_reduce<VARIANT, 1, true, FINEST>), grid, block, 0, s, p);
     } else if (weight_mode == 0) {
-        hipLaunchKernelGGL((k_reduce<VARIANT, 0, false>), grid, block, 0, s, p);
+        hipLaunchKernelGGL((k_reduce<VARIANT, 0, false, FINEST>), grid, block, 0, s, p);
     } else if (weight_mode == 1) {
-        hipLaunchKernelGGL((k_reduce<VARIANT, 1, false>), grid, block, 0, s, p);
+        hipLaunchKernelGGL((k_reduce<VARIANT, 1, false, FINEST>), grid, block, 0, s, p);
     } else {
-        hipLaunchKernelGGL((k_reduce<VARIANT, 2, false>), grid, block, 0, s, p);
+        hipLaunchKernelGGL((k_reduce<VARIANT, 2, false, FINEST>), grid, block, 0, s, p);
     }
     return hipGetLastError();
 }
 
 hipError_t dvo_launch_reduce(const DvoReduceParams& p, int variant, int weight_mode, int scale_pass, hipStream_t s)
 {
-    if (variant == 0) return launch_reduce_v<0>(p, weight_mode, scale_pass, s);
-    return launch_reduce_v<1>(p, weight_mode, scale_pass, s);
+    if (p.finest) {
+        if (variant == 0) return launch_reduce_v<0, true>(p, weight_mode, scale_pass, s);
+        return launch_reduce_v<1, true>(p, weight_mode, scale_pass, s);
+    }
+    if (variant == 0) return launch_reduce_v<0, false>(p, weight_mode, scale_pass, s);
+    return launch_reduce_v<1, false>(p, weight_mode, scale_pass, s);
 }
 
 // ================================================================================================
