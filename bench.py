@@ -27,6 +27,21 @@ ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT / "dense-visual-odometry_amd"))
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s spec, ~6.3 achievable)
+PMC_FILE = ROOT / "profiles" / "pmc_traffic.json"   # HBM bytes per launch from rocprofv3 --pmc passes (tools/profile_gpu.sh)
+
+
+def recorded_traffic(kernel_pairs, width, height):
+    """HBM bytes per level-0 launch measured with rocprofv3 PMC counters (separate FETCH_SIZE / WRITE_SIZE passes,
+    gfx950 x2 read correction) for the same launch shape, or None.  PMC counters cannot be read from inside this
+    process; the value is the committed measurement of the same command (profiles/)."""
+    try:
+        rec = json.loads(PMC_FILE.read_text())
+        for e in rec["entries"]:
+            if e["pairs_per_launch"] == kernel_pairs and e["width"] == width and e["height"] == height:
+                return e
+    except Exception:
+        pass
+    return None
 
 
 def parse_args():
@@ -34,12 +49,13 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=256, help="frame pairs per GPU per step")
+    ap.add_argument("--batch", type=int, default=512, help="frame pairs per GPU per step")
     ap.add_argument("--width", type=int, default=640)
     ap.add_argument("--height", type=int, default=480)
     ap.add_argument("--levels", type=int, default=4)
     ap.add_argument("--iterations", type=int, default=10)
     ap.add_argument("--weighting", default="none", choices=["none", "student_t_reference", "huber"])
+    ap.add_argument("--streams", type=int, default=2, help="independent HIP streams (sub-batches) per GPU")
     ap.add_argument("--distinct", type=int, default=0, help="distinct rendered frames (0 = batch+1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-pairs", type=int, default=8)
@@ -90,7 +106,7 @@ def main():
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
 
     from dvo_amd import synthetic
-    from dvo_amd.batch import BatchAligner, pose_records, allgather_poses
+    from dvo_amd.batch import StreamedAligner, pose_records, allgather_poses
 
     B, W, H, L = args.batch, args.width, args.height, args.levels
     n_frames = B + 1
@@ -105,14 +121,12 @@ def main():
     torch.cuda.synchronize()
     valid_l0 = float((depth[:-1] != 0).sum().item()) / B            # measured V per pair at level 0
 
-    al = BatchAligner(st["K"], st["depth_scale"], W, H, L, max_pairs=B, device=local_rank,
-                      max_iterations=args.iterations, weighting=args.weighting)
+    al = StreamedAligner(st["K"], st["depth_scale"], W, H, L, max_pairs=B, n_streams=args.streams, device=local_rank,
+                         max_iterations=args.iterations, weighting=args.weighting)
     counts = [B] * world
 
     def step():
-        al.ingest_device(gray.data_ptr(), depth.data_ptr(), n_frames)
-        al.solve_enqueue(n_frames)
-        res = al.solve_fetch(n_frames)
+        res = al.align_device(gray.data_ptr(), depth.data_ptr(), n_frames)
         if world > 1:
             allgather_poses(pose_records(res["T"], res["iters"], res["err"]), counts, device="cuda")
         return res
@@ -123,7 +137,7 @@ def main():
         raise SystemExit("non-finite poses in warm-up")
 
     def fence():
-        al.ctx.synchronize()
+        al.synchronize()
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
@@ -141,18 +155,23 @@ def main():
     iters_total = int(res["iters"].sum())
 
     # --- roofline leg: same steps again with every reduction launch bracketed by HIP events ----------------
-    al.ctx.profile_enable(True)
-    al.ctx.profile_read(reset=True)
+    # (run on ONE stream so that each timed launch has the GPU to itself, like the rocprofv3 kernel trace)
+    prof = al.parts[0]
+    npr = min(B, prof.max_pairs)
+    prof.ctx.profile_enable(True)
+    prof.ctx.profile_read(reset=True)
     prof_steps = max(1, min(args.steps, 5))
     for _ in range(prof_steps):
-        step()
-    launches, ms = al.ctx.profile_read(reset=True)
-    al.ctx.profile_enable(False)
+        prof.ingest_device(gray.data_ptr(), depth.data_ptr(), npr + 1)
+        prof.solve_enqueue(npr + 1)
+        prof.solve_fetch(npr + 1)
+    launches, ms = prof.ctx.profile_read(reset=True)
+    prof.ctx.profile_enable(False)
 
     if rank == 0:
         P0 = W * H
-        alg_bytes = (2.0 * P0 + 10.0 * valid_l0) * B                  # SURVEY 8d, per level-0 launch
-        layout_bytes = (2.0 * P0 + 5.0 * valid_l0) * B                # this build's packed layout
+        alg_bytes = (2.0 * P0 + 10.0 * valid_l0) * npr                # SURVEY 8d, per level-0 launch
+        layout_bytes = (2.0 * P0 + 5.0 * valid_l0) * npr              # this build's packed layout
         avg_ms = ms[0] / max(launches[0], 1)
         achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
         per_level = {str(l): {"launches": int(launches[l]), "avg_us": (1e3 * ms[l] / launches[l]) if launches[l] else None}
@@ -170,13 +189,15 @@ def main():
             "config": {"workload": "synthetic %dx%d RGB-D stream, %d-level pyramid, %d GN iterations/level, "
                                    "%d frame pairs per GPU per step (pyramid+Sobel build and device-side GN solve "
                                    "inside the timed region), weighting=%s" % (W, H, L, args.iterations, B, args.weighting),
-                       "batch_pairs_per_gpu": B, "distinct_frames": int(min(n_distinct, n_frames)),
+                       "batch_pairs_per_gpu": B, "streams_per_gpu": args.streams, "distinct_frames": int(min(n_distinct, n_frames)),
                        "gn_iterations_per_pair": iters_total / B,
                        "gn_iterations_per_s": world * iters_total * args.steps / elapsed,
                        "parallelism": "1 independent stream per GPU, RCCL all-gather of pose records"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "kernel": "k_reduce<V1> level 0 (%dx%d), %d pairs per launch" % (W, H, B),
+                         "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": (recorded_traffic(npr, W, H) or {}).get("hbm_bytes_per_launch"),
+                         "traffic_source": (recorded_traffic(npr, W, H) or {}).get("source"),
+                         "kernel": "k_reduce<V1,finest> level 0 (%dx%d), %d pairs per launch" % (W, H, npr),
                          "avg_launch_us": 1e3 * avg_ms, "launches_timed": int(launches[0]),
                          "algorithmic_bytes_per_launch": alg_bytes,
                          "layout_bytes_per_launch": layout_bytes,

@@ -242,7 +242,7 @@ int fill_reduce_params(dvo_ctx* ctx, int level, int n_pairs, int w, int h, DvoRe
     p->T = ctx->d_T;
     p->wparam = ctx->d_wparam;
     p->active = nullptr;
-    p->finest = (level == 0) ? 1 : 0;
+    p->finest = (level == 0) ? (ctx->profiling ? 2 : 1) : 0;
     p->partials = ctx->d_partials;
     {
         const char* e = getenv("DVO_XCD_REMAP");

@@ -372,8 +372,9 @@ __device__ __forceinline__ double wave_sum(double v)
 #ifndef DVO_REDUCE_WAVES_PER_SIMD
 #define DVO_REDUCE_WAVES_PER_SIMD 4
 #endif
-// FINEST only tags the instantiation (level 0 gets its own kernel name in rocprofv3 --stats); codegen is identical.
-template <int VARIANT, int WMODE, bool SCALE_PASS, bool FINEST>
+// TAG only names the instantiation so that rocprofv3 --stats lists these dispatches on their own line; codegen is
+// identical.  0: coarser levels, 1: level 0, 2: level 0 while the ctx is in profiling mode (bench.py's roofline leg).
+template <int VARIANT, int WMODE, bool SCALE_PASS, int TAG>
 __global__ __launch_bounds__(DVO_BLOCK, DVO_REDUCE_WAVES_PER_SIMD) void k_reduce(const DvoReduceParams p)
 {
     constexpr int NACC = SCALE_PASS ? 1 : DVO_NACC;
@@ -464,7 +465,7 @@ __global__ __launch_bounds__(DVO_BLOCK, DVO_REDUCE_WAVES_PER_SIMD) void k_reduce
                 dvo_finish<VARIANT, !SCALE_PASS>(p.cam, geo[j], taps[j], ii[j], o);
                 const float r = o.r;
                 const float r2 = r * r;
-                if (SCALE_PASS) {
+                if constexpr (SCALE_PASS) {
                     // r^2 * (dof+1)/(dof + r^2*lambda), dof = 5 (weighter/t_weighter.py:43-45)
                     acc[0] += r2 * (6.0f * fast_rcp(fmaf(r2, wpar, 5.0f)));
                 } else {
@@ -489,13 +490,13 @@ __global__ __launch_bounds__(DVO_BLOCK, DVO_REDUCE_WAVES_PER_SIMD) void k_reduce
         }
     }
 
-    if (!SCALE_PASS && WMODE == 0) acc[NACC - 1] = acc[NACC - 3];     // sum r^2 == sum w r^2 when w == 1
+    if constexpr (!SCALE_PASS && WMODE == 0) acc[NACC - 1] = acc[NACC - 3];     // sum r^2 == sum w r^2 when w == 1
     // Workgroup reduction.  float32 only inside one lane; everything across lanes / waves / workgroups is float64.
     // The 30 per-lane sums are transposed through LDS instead of 30 x 6 cross-lane butterflies: every lane stores
     // its sums ([term][thread], padded so stores and loads are bank-conflict free), then 8 lanes per term each add
     // 32 of the 256 values in float64 (fixed order => reproducible), and a 3-step shuffle joins the 8 segments.
     // Two rounds of 15 terms keep the LDS footprint at 15.5 KB per workgroup.
-    if (SCALE_PASS) {
+    if constexpr (SCALE_PASS) {
         __shared__ double lds1[DVO_BLOCK / 64];
         const double sw = wave_sum((double)acc[0]);
         if ((threadIdx.x & 63) == 0) lds1[threadIdx.x >> 6] = sw;
@@ -534,30 +535,34 @@ __global__ __launch_bounds__(DVO_BLOCK, DVO_REDUCE_WAVES_PER_SIMD) void k_reduce
     }
 }
 
-template <int VARIANT, bool FINEST>
+template <int VARIANT, int TAG>
 static hipError_t launch_reduce_v(const DvoReduceParams& p, int weight_mode, int scale_pass, hipStream_t s)
 {
     dim3 grid((unsigned)(p.n_pairs * p.blocks_per_pair)), block(DVO_BLOCK);
     if (scale_pass) {
-        hipLaunchKernelGGL((k_reduce<VARIANT, 1, true, FINEST>), grid, block, 0, s, p);
+        hipLaunchKernelGGL((k_reduce<VARIANT, 1, true, TAG>), grid, block, 0, s, p);
     } else if (weight_mode == 0) {
-        hipLaunchKernelGGL((k_reduce<VARIANT, 0, false, FINEST>), grid, block, 0, s, p);
+        hipLaunchKernelGGL((k_reduce<VARIANT, 0, false, TAG>), grid, block, 0, s, p);
     } else if (weight_mode == 1) {
-        hipLaunchKernelGGL((k_reduce<VARIANT, 1, false, FINEST>), grid, block, 0, s, p);
+        hipLaunchKernelGGL((k_reduce<VARIANT, 1, false, TAG>), grid, block, 0, s, p);
     } else {
-        hipLaunchKernelGGL((k_reduce<VARIANT, 2, false, FINEST>), grid, block, 0, s, p);
+        hipLaunchKernelGGL((k_reduce<VARIANT, 2, false, TAG>), grid, block, 0, s, p);
     }
     return hipGetLastError();
 }
 
 hipError_t dvo_launch_reduce(const DvoReduceParams& p, int variant, int weight_mode, int scale_pass, hipStream_t s)
 {
-    if (p.finest) {
-        if (variant == 0) return launch_reduce_v<0, true>(p, weight_mode, scale_pass, s);
-        return launch_reduce_v<1, true>(p, weight_mode, scale_pass, s);
+    if (p.finest == 2) {
+        if (variant == 0) return launch_reduce_v<0, 2>(p, weight_mode, scale_pass, s);
+        return launch_reduce_v<1, 2>(p, weight_mode, scale_pass, s);
     }
-    if (variant == 0) return launch_reduce_v<0, false>(p, weight_mode, scale_pass, s);
-    return launch_reduce_v<1, false>(p, weight_mode, scale_pass, s);
+    if (p.finest == 1) {
+        if (variant == 0) return launch_reduce_v<0, 1>(p, weight_mode, scale_pass, s);
+        return launch_reduce_v<1, 1>(p, weight_mode, scale_pass, s);
+    }
+    if (variant == 0) return launch_reduce_v<0, 0>(p, weight_mode, scale_pass, s);
+    return launch_reduce_v<1, 0>(p, weight_mode, scale_pass, s);
 }
 
 // ================================================================================================

@@ -78,6 +78,50 @@ class BatchAligner:
         return self.solve_fetch(gray.shape[0])
 
 
+class StreamedAligner:
+    """`n_streams` BatchAligners (one HIP stream each) on one GPU working on disjoint slices of a window of
+    frames.  The GN loop of a slice is a chain of dependent launches (reduce -> solve -> reduce ...); with two or
+    more independent chains in flight the GPU fills the bubbles of one chain (tiny solve kernels, launch gaps,
+    the tail of each reduction) with work of another."""
+
+    def __init__(self, K, depth_scale, width=640, height=480, levels=4, max_pairs=64, n_streams=2, device=0, **kw):
+        if n_streams < 1 or max_pairs < n_streams:
+            raise ValueError("need 1 <= n_streams <= max_pairs")
+        self.n_streams, self.max_pairs = n_streams, max_pairs
+        self.width, self.height = width, height
+        per = (max_pairs + n_streams - 1) // n_streams
+        self.parts = [BatchAligner(K, depth_scale, width, height, levels, max_pairs=per, device=device, **kw)
+                      for _ in range(n_streams)]
+        self.ctx = self.parts[0].ctx
+
+    def close(self):
+        for a in self.parts:
+            a.close()
+
+    def _slices(self, n_frames):
+        n_pairs = n_frames - 1
+        out = []
+        for s in range(self.n_streams):
+            lo, hi = shard_pairs(n_pairs, s, self.n_streams)
+            if hi > lo:
+                out.append((self.parts[s], lo, hi))
+        return out
+
+    def align_device(self, d_gray_ptr: int, d_depth_ptr: int, n_frames: int):
+        """Frames [n][h][w] resident in HBM (u8 gray, u16 depth) -> dict(T, xi, iters, err) for the n-1 pairs."""
+        npx = self.width * self.height
+        sl = self._slices(n_frames)
+        for a, lo, hi in sl:                                   # enqueue everything first, then fetch
+            a.ingest_device(d_gray_ptr + lo * npx, d_depth_ptr + 2 * lo * npx, hi - lo + 1)
+            a.solve_enqueue(hi - lo + 1)
+        res = [a.solve_fetch(hi - lo + 1) for a, lo, hi in sl]
+        return {k: np.concatenate([r[k] for r in res], axis=0) for k in res[0]}
+
+    def synchronize(self):
+        for a in self.parts:
+            a.ctx.synchronize()
+
+
 # -- sharding over GPUs ------------------------------------------------------------------------------
 def shard_pairs(n_pairs: int, rank: int, world_size: int) -> Tuple[int, int]:
     """Contiguous range [lo, hi) of pair indices owned by `rank` (pair i = frames (i, i+1); a rank needs

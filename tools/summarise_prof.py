@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
-"""Summarises rocprofv3 CSV output (kernel stats + PMC passes) per kernel name."""
+"""Summarises rocprofv3 CSV output (kernel stats + PMC passes) for this repo's kernels."""
 import csv
 import glob
+import re
 import sys
 from collections import defaultdict
 
@@ -9,44 +10,52 @@ root = sys.argv[1]
 
 
 def short(name):
-    name = name.split("(")[0]
-    return name[-70:]
+    name = re.sub(r"\(.*$", "", name)
+    return name.replace("void ", "")[-64:]
 
 
+print(open(root + "/command.txt").read().strip())
 for f in glob.glob(root + "/trace/**/*kernel_stats.csv", recursive=True):
-    print("== kernel stats:", f)
+    print("== rocprofv3 --kernel-trace --stats (this repo's kernels; torch kernels of the synthetic-stream renderer omitted)")
     with open(f) as fp:
         rows = list(csv.DictReader(fp))
-    for r in rows[:14]:
-        print("  %-72s calls %6s  total_ns %12s  avg_ns %10s  pct %6s" % (
-            short(r.get("Name", "")), r.get("Calls"), r.get("TotalDurationNs"), r.get("AverageNs"), r.get("Percentage")))
+    print("  %-64s %8s %14s %12s %12s %12s" % ("kernel", "calls", "total_us", "avg_us", "min_us", "max_us"))
+    for r in rows:
+        n = r.get("Name", "")
+        if "k_reduce" in n or n.startswith("k_") or "k_batch" in n:
+            print("  %-64s %8s %14.1f %12.2f %12.2f %12.2f" % (short(n), r["Calls"], float(r["TotalDurationNs"]) / 1e3,
+                                                            float(r["AverageNs"]) / 1e3, float(r["MinNs"]) / 1e3, float(r["MaxNs"]) / 1e3))
 
-# per-dispatch durations by grid size for the reduction kernel
 for f in glob.glob(root + "/trace/**/*kernel_trace.csv", recursive=True):
     with open(f) as fp:
         rows = list(csv.DictReader(fp))
     agg = defaultdict(list)
+    meta = {}
     for r in rows:
-        if "k_reduce" in r.get("Kernel_Name", ""):
-            key = (short(r["Kernel_Name"]), r.get("Grid_Size_X") or r.get("Grid_Size"), r.get("VGPR_Count"), r.get("SGPR_Count"), r.get("LDS_Block_Size"))
+        n = r.get("Kernel_Name", "")
+        if "k_reduce" in n:
+            key = short(n)
             agg[key].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
-    print("== k_reduce dispatches by grid:")
-    for k, v in sorted(agg.items(), key=lambda kv: -sum(kv[1])):
-        print("  %s grid=%s vgpr=%s sgpr=%s lds=%s  n=%d avg_us=%.1f" % (k[0], k[1], k[2], k[3], k[4], len(v), sum(v) / len(v) / 1e3))
+            meta[key] = (r.get("Grid_Size_X") or r.get("Grid_Size"), r.get("Workgroup_Size_X") or r.get("Workgroup_Size"),
+                         r.get("VGPR_Count"), r.get("Accum_VGPR_Count"), r.get("SGPR_Count"), r.get("LDS_Block_Size"), r.get("Scratch_Size"))
+    print("== k_reduce dispatch metadata (grid, wg, arch_vgpr, accum_vgpr, sgpr, lds, scratch) and median duration")
+    for k, v in sorted(agg.items()):
+        v = sorted(v)
+        print("  %-64s %s  n=%d median_us=%.2f" % (k, meta[k], len(v), v[len(v) // 2] / 1e3))
 
-for p in sorted(glob.glob(root + "/pmc*")):
+for p in sorted(glob.glob(root + "/pmc_*")):
     for f in glob.glob(p + "/**/*counter_collection.csv", recursive=True):
         with open(f) as fp:
             rows = list(csv.DictReader(fp))
         agg = defaultdict(lambda: defaultdict(float))
         cnt = defaultdict(int)
         for r in rows:
-            k = (short(r.get("Kernel_Name", "")), r.get("Grid_Size"))
+            k = short(r.get("Kernel_Name", ""))
             agg[k][r["Counter_Name"]] += float(r["Counter_Value"])
             cnt[(k, r["Counter_Name"])] += 1
-        print("== PMC:", f)
-        for k, c in sorted(agg.items(), key=lambda kv: -max(kv[1].values()))[:8]:
-            print("  %s grid=%s" % k)
-            for name, val in c.items():
-                n = cnt[(k, name)]
-                print("      %-24s per-dispatch %.4g  (n=%d)" % (name, val / n, n))
+        print("== PMC pass %s (per-dispatch averages)" % p.split("/")[-1])
+        for k, c in sorted(agg.items()):
+            line = "  %-64s" % k
+            for name, val in sorted(c.items()):
+                line += "  %s=%.4g" % (name, val / cnt[(k, name)])
+            print(line + "  (n=%d)" % max(cnt[(k, nm)] for nm in c))
