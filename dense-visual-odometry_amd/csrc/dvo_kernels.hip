@@ -245,7 +245,7 @@ struct PixelOut {
 struct PixelGeo {
     float x, y, z;       // back-projected point (un-warped)
     float uw, vw;        // warped pixel coordinates
-    int off;             // offset of tap (y0, x0) in the packed plane (0 when !ok, so the load is harmless)
+    unsigned off;        // offset of tap (y0, x0) in the packed plane (0 when !ok, so the load is harmless)
     bool ok;             // depth != 0 && warped point inside the closed image rectangle
 };
 
@@ -285,8 +285,8 @@ __device__ __forceinline__ void dvo_geo(const DvoLevelGeom& g, const DvoLevelCam
                                         const float* __restrict__ T, int ux, int vy, unsigned d, PixelGeo& o)
 {
     o.ok = false;
-    o.off = 0;
-    o.x = o.y = o.z = 0.0f;
+    o.off = 0u;
+    o.x = o.y = o.z = 0.0f;             // (leaving these unset makes LLVM copy all 30 accumulators at every join)
     o.uw = o.vw = __builtin_nanf("");
     if (d == 0u) return;                                      // mask = depth != 0 (camera_model.py:195)
     // --- deproject (camera_model.py:195-221) -------------------------------------------------------
@@ -307,7 +307,7 @@ __device__ __forceinline__ void dvo_geo(const DvoLevelGeom& g, const DvoLevelCam
     // closed-boundary rule: valid <=> 0 <= x <= W-1 and 0 <= y <= H-1 ; NaN compares false
     const bool ok = (uw >= 0.0f) && (uw <= (float)(g.w - 1)) && (vw >= 0.0f) && (vw <= (float)(g.h - 1));
     o.x = x; o.y = y; o.z = z; o.uw = uw; o.vw = vw; o.ok = ok;
-    o.off = ok ? ((int)floorf(vw) * g.pitch + (int)floorf(uw)) : 0;
+    o.off = ok ? (unsigned)((int)floorf(vw) * g.pitch + (int)floorf(uw)) : 0u;
 }
 
 __device__ __forceinline__ void dvo_load_taps(const DvoLevelGeom& g, const uint32_t* __restrict__ cur,
@@ -451,7 +451,7 @@ __global__ __launch_bounds__(DVO_BLOCK, DVO_REDUCE_WAVES_PER_SIMD) void k_reduce
         for (int j = 0; j < DVO_PX_PER_THREAD; ++j) {
             dvo_geo(p.g, p.cam, p.depth_scale, T, ux, vy, dd[j], geo[j]);
             dvo_load_taps(p.g, packed_cur, geo[j], taps[j]);
-            if (VARIANT == 1) taps[j].own = geo[j].ok ? packed_prev[(size_t)vy * p.g.pitch + ux] : 0u;
+            if (VARIANT == 1) taps[j].own = geo[j].ok ? packed_prev[(unsigned)(vy * p.g.pitch + ux)] : 0u;
             ux += 64;
             while (ux >= p.g.w) { ux -= p.g.w; ++vy; }
         }
@@ -619,6 +619,7 @@ __global__ __launch_bounds__(DVO_BLOCK) void k_dense(const DvoDenseParams p)
     PixelOut o;
     PixelGeo q;
     q.ok = false;
+    q.x = q.y = q.z = 0.0f;
     q.uw = q.vw = __builtin_nanf("");
     o.r = 0.0f;
 #pragma unroll
