@@ -33,6 +33,13 @@ struct HostStage {          // pinned staging for the small per-call arrays
 
 }  // namespace
 
+struct SolveKey {
+    int n_pairs, w, h, levels, max_iterations, max_increased, variant, weight_mode, has_init, trace_cap;
+    double tolerance, weight_param;
+    const void* trace;
+    const void* stream;
+};
+
 struct dvo_ctx {
     int device = 0;
     hipStream_t own_stream = nullptr;
@@ -77,6 +84,10 @@ struct dvo_ctx {
     std::vector<hipEvent_t> ev_pool;
     int64_t prof_launches[DVO_MAX_LEVELS] = {0};
     double prof_ms[DVO_MAX_LEVELS] = {0};
+    // hipGraph cache of the device-side solve
+    struct GraphEntry { SolveKey key; hipGraphExec_t exec; };
+    std::vector<GraphEntry> graphs;
+    bool graphs_enabled = true;
     char err[512] = "";
 };
 
@@ -269,21 +280,19 @@ int fill_reduce_params(dvo_ctx* ctx, int level, int n_pairs, int w, int h, DvoRe
 
 int build_pyramid_on_device(dvo_ctx* ctx, int slot, int w, int h, int levels)
 {
-    DvoLevelGeom g[DVO_MAX_LEVELS];
-    level_geometry(w, h, levels, g, nullptr);
-    uint8_t* base = ctx->d_slots + (size_t)slot * ctx->slot_stride;
-    for (int l = 0; l < levels; ++l) {
-        uint8_t* gray = base + g[l].off_gray;
-        uint16_t* depth = reinterpret_cast<uint16_t*>(base + g[l].off_depth);
-        uint32_t* packed = reinterpret_cast<uint32_t*>(base + g[l].off_packed);
-        if (l > 0) {
-            const uint8_t* pg = base + g[l - 1].off_gray;
-            const uint16_t* pd = reinterpret_cast<const uint16_t*>(base + g[l - 1].off_depth);
-            HIP_TRY(ctx, dvo_launch_median_down_u8(pg, g[l - 1].w, g[l - 1].h, gray, ctx->stream));
-            HIP_TRY(ctx, dvo_launch_median_down_u16(pd, g[l - 1].w, g[l - 1].h, depth, ctx->stream));
-        }
-        HIP_TRY(ctx, dvo_launch_sobel_pack(gray, g[l].w, g[l].h, packed, g[l].pitch, ctx->stream));
-    }
+    // level 0 is already in the slot; the batched ingest kernels build the rest (n_frames = 1)
+    DvoBatchIngestParams p;
+    p.slots = ctx->d_slots;
+    p.slot_stride = ctx->slot_stride;
+    p.slot_ids = ctx->d_frame_slots;
+    p.src_gray = nullptr;
+    p.src_depth = nullptr;
+    p.n_frames = 1;
+    p.levels = levels;
+    level_geometry(w, h, levels, p.g, nullptr);
+    ctx->h_frame_slots[0] = slot;
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->d_frame_slots, ctx->h_frame_slots, sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, dvo_launch_batch_ingest(p, ctx->stream));
     return DVO_OK;
 }
 
@@ -374,6 +383,10 @@ int dvo_create(int device, int max_w, int max_h, int max_levels, int n_slots, in
     CREATE_TRY(hipEventCreate(&ctx->tm_a));
     CREATE_TRY(hipEventCreate(&ctx->tm_b));
     CREATE_TRY(hipStreamSynchronize(ctx->stream));
+    {
+        const char* e = getenv("DVO_GRAPH");
+        ctx->graphs_enabled = !(e && e[0] == '0');
+    }
 #undef CREATE_TRY
     *out = ctx;
     return DVO_OK;
@@ -386,6 +399,7 @@ void dvo_destroy(dvo_ctx* ctx)
     if (ctx->own_stream) (void)hipStreamSynchronize(ctx->own_stream);
     drain_profile(ctx);
     for (hipEvent_t e : ctx->ev_pool) (void)hipEventDestroy(e);
+    for (auto& g : ctx->graphs) (void)hipGraphExecDestroy(g.exec);
     if (ctx->tm_a) (void)hipEventDestroy(ctx->tm_a);
     if (ctx->tm_b) (void)hipEventDestroy(ctx->tm_b);
     void* dev[] = {ctx->d_slots, ctx->d_prev, ctx->d_cur, ctx->d_T, ctx->d_Tinit, ctx->d_wparam, ctx->d_active, ctx->d_partials,
@@ -691,27 +705,13 @@ int dvo_residuals_jacobian(dvo_ctx* ctx, int level, int prev_slot, int cur_slot,
     return DVO_OK;
 }
 
-int dvo_solve_batch_enqueue(dvo_ctx* ctx, int n_pairs, const int* prev_slot, const int* cur_slot, int levels,
-                            int max_iterations, double tolerance, int max_increased_steps_allowed, int variant,
-                            int weight_mode, double weight_param, const float* T_init)
+// Enqueues (or, under stream capture, records) the launch sequence of one batched coarse-to-fine solve.
+static int record_solve(dvo_ctx* ctx, const SolveKey& k, const float* d_init)
 {
-    if (!ctx) return DVO_ERR_INVALID_ARG;
-    if (levels < 1 || max_iterations < 0) return fail(ctx, DVO_ERR_INVALID_ARG, "levels %d / max_iterations %d invalid", levels, max_iterations);
-    if (weight_mode < 0 || weight_mode > 2) return fail(ctx, DVO_ERR_INVALID_ARG, "weight_mode %d unknown", weight_mode);
-    HIP_TRY(ctx, hipSetDevice(ctx->device));
-    int rc = check_variant(ctx, variant);
-    if (rc) return rc;
-    int w, h;
-    rc = check_pairs(ctx, n_pairs, prev_slot, cur_slot, levels - 1, &w, &h);
-    if (rc) return rc;
-    rc = stage_pairs(ctx, n_pairs, prev_slot, cur_slot, nullptr, nullptr);
-    if (rc) return rc;
-    const float* d_init = nullptr;
-    if (T_init) {
-        memcpy(ctx->hs.T, T_init, (size_t)n_pairs * 12 * sizeof(float));
-        HIP_TRY(ctx, hipMemcpyAsync(ctx->d_Tinit, ctx->hs.T, (size_t)n_pairs * 12 * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
-        d_init = ctx->d_Tinit;
-    }
+    const int n_pairs = k.n_pairs, w = k.w, h = k.h, levels = k.levels, max_iterations = k.max_iterations;
+    const int variant = k.variant, weight_mode = k.weight_mode, max_increased_steps_allowed = k.max_increased;
+    const double tolerance = k.tolerance, weight_param = k.weight_param;
+    int rc;
     const double lambda0 = 1.0 / 25.0;                      // TDistributionWeighter: initial_sigma = 5 (t_weighter.py:11-15)
     HIP_TRY(ctx, dvo_launch_init_state(ctx->d_state, ctx->d_T, d_init, n_pairs, lambda0, ctx->stream));
     for (int level = levels - 1; level >= 0; --level) {
@@ -751,6 +751,62 @@ int dvo_solve_batch_enqueue(dvo_ctx* ctx, int n_pairs, const int* prev_slot, con
     }
     HIP_TRY(ctx, dvo_launch_finish(ctx->d_state, n_pairs, ctx->d_xi, ctx->d_iters, ctx->d_err, ctx->stream));
     return DVO_OK;
+}
+
+
+int dvo_solve_batch_enqueue(dvo_ctx* ctx, int n_pairs, const int* prev_slot, const int* cur_slot, int levels,
+                            int max_iterations, double tolerance, int max_increased_steps_allowed, int variant,
+                            int weight_mode, double weight_param, const float* T_init)
+{
+    if (!ctx) return DVO_ERR_INVALID_ARG;
+    if (levels < 1 || max_iterations < 0) return fail(ctx, DVO_ERR_INVALID_ARG, "levels %d / max_iterations %d invalid", levels, max_iterations);
+    if (weight_mode < 0 || weight_mode > 2) return fail(ctx, DVO_ERR_INVALID_ARG, "weight_mode %d unknown", weight_mode);
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    int rc = check_variant(ctx, variant);
+    if (rc) return rc;
+    int w, h;
+    rc = check_pairs(ctx, n_pairs, prev_slot, cur_slot, levels - 1, &w, &h);
+    if (rc) return rc;
+    rc = stage_pairs(ctx, n_pairs, prev_slot, cur_slot, nullptr, nullptr);
+    if (rc) return rc;
+    const float* d_init = nullptr;
+    if (T_init) {
+        memcpy(ctx->hs.T, T_init, (size_t)n_pairs * 12 * sizeof(float));
+        HIP_TRY(ctx, hipMemcpyAsync(ctx->d_Tinit, ctx->hs.T, (size_t)n_pairs * 12 * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+        d_init = ctx->d_Tinit;
+    }
+    // The launch sequence of the whole solve is fixed by (batch size, image size, levels, iterations, modes): it is
+    // captured once into a hipGraph and replayed, which removes the per-launch host cost of the ~2*levels*iterations
+    // dependent launches (the loop is launch-bound for small batches).  Slot ids / initial poses are read by the
+    // kernels from fixed device buffers refreshed above, so they are not part of the key.
+    SolveKey key;
+    memset(&key, 0, sizeof(key));
+    key.n_pairs = n_pairs; key.w = w; key.h = h; key.levels = levels; key.max_iterations = max_iterations;
+    key.max_increased = max_increased_steps_allowed; key.variant = variant; key.weight_mode = weight_mode;
+    key.tolerance = tolerance; key.weight_param = weight_param; key.has_init = T_init ? 1 : 0;
+    key.trace = ctx->d_trace; key.trace_cap = ctx->trace_cap; key.stream = ctx->stream;
+    const bool use_graph = ctx->graphs_enabled && !ctx->profiling;
+    if (use_graph) {
+        for (auto& g : ctx->graphs)
+            if (memcmp(&g.key, &key, sizeof(key)) == 0) {
+                HIP_TRY(ctx, hipGraphLaunch(g.exec, ctx->stream));
+                return DVO_OK;
+            }
+        hipGraph_t graph = nullptr;
+        hipGraphExec_t exec = nullptr;
+        HIP_TRY(ctx, hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
+        rc = record_solve(ctx, key, d_init);
+        hipError_t e = hipStreamEndCapture(ctx->stream, &graph);
+        if (rc) { if (graph) (void)hipGraphDestroy(graph); return rc; }
+        HIP_TRY(ctx, e);
+        HIP_TRY(ctx, hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+        (void)hipGraphDestroy(graph);
+        if (ctx->graphs.size() >= 16) { (void)hipGraphExecDestroy(ctx->graphs.front().exec); ctx->graphs.erase(ctx->graphs.begin()); }
+        ctx->graphs.push_back({key, exec});
+        HIP_TRY(ctx, hipGraphLaunch(exec, ctx->stream));
+        return DVO_OK;
+    }
+    return record_solve(ctx, key, d_init);
 }
 
 int dvo_solve_batch_fetch(dvo_ctx* ctx, int n_pairs, float* T_out, double* xi_out, int* iters_out, double* err_out)

@@ -104,9 +104,6 @@ struct DvoBatchIngestParams {
 };
 
 // launch wrappers implemented in dvo_kernels.hip -------------------------------------------------
-hipError_t dvo_launch_median_down_u8(const uint8_t* src, int sw, int sh, uint8_t* dst, hipStream_t s);
-hipError_t dvo_launch_median_down_u16(const uint16_t* src, int sw, int sh, uint16_t* dst, hipStream_t s);
-hipError_t dvo_launch_sobel_pack(const uint8_t* gray, int w, int h, uint32_t* packed, int pitch, hipStream_t s);
 hipError_t dvo_launch_bgr_ingest(const uint8_t* bgr, const uint16_t* depth_in, int w, int h, uint8_t* gray,
                                  uint16_t* depth_out, double depth_scale, double max_distance, hipStream_t s);
 hipError_t dvo_launch_batch_ingest(const DvoBatchIngestParams& p, hipStream_t s);

@@ -5,8 +5,8 @@
 // in-bounds decision of every pixel is bit-identical; everywhere an FMA is wanted it is written fmaf().
 //
 // Kernels
-//   k_median_down<T>   K1  3x3 median (replicated border) + keep even rows/cols   (utils/image_pyramid.py:19-21)
-//   k_sobel_pack       K2  Sobel 3x3 BORDER_REFLECT, packed with the intensity     (utils/jacobian.py:47-73)
+//   k_batch_median_down K1 3x3 median (replicated border) + keep even rows/cols, u8+u16, 4 px/lane (utils/image_pyramid.py:19-21)
+//   k_batch_sobel_pack K2  Sobel 3x3 BORDER_REFLECT, packed with the intensity, 4 px/lane (utils/jacobian.py:47-73)
 //   k_bgr_ingest       K0  BGR->gray fixed point + depth clamp                     (core/base_dense_visual_odometry.py:58-59)
 //   k_reduce<...>      K3  residual + Jacobian + weight + 30-term reduction        (cpu_robust...:134-200 + base_robust_dvo.py:168-188)
 //                          (scale_pass form = K3s, weighter/t_weighter.py:36-47)
@@ -35,70 +35,6 @@ __device__ __forceinline__ unsigned median9(unsigned p0, unsigned p1, unsigned p
     DVO_CSWAP(p4, p7); DVO_CSWAP(p4, p2); DVO_CSWAP(p6, p4);
     DVO_CSWAP(p4, p2);
     return p4;
-}
-
-template <typename T>
-__global__ __launch_bounds__(DVO_BLOCK) void k_median_down(const T* __restrict__ src, int sw, int sh,
-                                                           T* __restrict__ dst, int dw, int dh)
-{
-    int x = blockIdx.x * 64 + (threadIdx.x & 63);
-    int y = blockIdx.y * 4 + (threadIdx.x >> 6);
-    if (x >= dw || y >= dh) return;
-    int cx = 2 * x, cy = 2 * y;
-    int xm = max(cx - 1, 0), xp = min(cx + 1, sw - 1);
-    int ym = max(cy - 1, 0), yp = min(cy + 1, sh - 1);
-    const T* r0 = src + (size_t)ym * sw;
-    const T* r1 = src + (size_t)cy * sw;
-    const T* r2 = src + (size_t)yp * sw;
-    unsigned m = median9(r0[xm], r0[cx], r0[xp], r1[xm], r1[cx], r1[xp], r2[xm], r2[cx], r2[xp]);
-    dst[(size_t)y * dw + x] = (T)m;
-}
-
-hipError_t dvo_launch_median_down_u8(const uint8_t* src, int sw, int sh, uint8_t* dst, hipStream_t s)
-{
-    int dw = (sw + 1) / 2, dh = (sh + 1) / 2;
-    dim3 grid((dw + 63) / 64, (dh + 3) / 4);
-    hipLaunchKernelGGL(k_median_down<uint8_t>, grid, dim3(DVO_BLOCK), 0, s, src, sw, sh, dst, dw, dh);
-    return hipGetLastError();
-}
-
-hipError_t dvo_launch_median_down_u16(const uint16_t* src, int sw, int sh, uint16_t* dst, hipStream_t s)
-{
-    int dw = (sw + 1) / 2, dh = (sh + 1) / 2;
-    dim3 grid((dw + 63) / 64, (dh + 3) / 4);
-    hipLaunchKernelGGL(k_median_down<uint16_t>, grid, dim3(DVO_BLOCK), 0, s, src, sw, sh, dst, dw, dh);
-    return hipGetLastError();
-}
-
-// ================================================================================================
-// K2: Sobel pack.  packed = I | (gx & 0xfff) << 8 | (gy & 0xfff) << 20 ; |gx|,|gy| <= 1020 < 2^11
-// ================================================================================================
-__global__ __launch_bounds__(DVO_BLOCK) void k_sobel_pack(const uint8_t* __restrict__ gray, int w, int h,
-                                                          uint32_t* __restrict__ packed, int pitch)
-{
-    int x = blockIdx.x * 64 + (threadIdx.x & 63);
-    int y = blockIdx.y * 4 + (threadIdx.x >> 6);
-    if (x >= w || y >= h) return;
-    // BORDER_REFLECT (fedcba|abcdefgh|hgfedcb) with radius 1 == index clamp
-    int xm = max(x - 1, 0), xp = min(x + 1, w - 1);
-    int ym = max(y - 1, 0), yp = min(y + 1, h - 1);
-    const uint8_t* r0 = gray + (size_t)ym * w;
-    const uint8_t* r1 = gray + (size_t)y * w;
-    const uint8_t* r2 = gray + (size_t)yp * w;
-    int p00 = r0[xm], p01 = r0[x], p02 = r0[xp];
-    int p10 = r1[xm], p11 = r1[x], p12 = r1[xp];
-    int p20 = r2[xm], p21 = r2[x], p22 = r2[xp];
-    int gx = (p02 + 2 * p12 + p22) - (p00 + 2 * p10 + p20);
-    int gy = (p20 + 2 * p21 + p22) - (p00 + 2 * p01 + p02);
-    uint32_t v = (uint32_t)p11 | (((uint32_t)gx & 0xfffu) << 8) | (((uint32_t)gy & 0xfffu) << 20);
-    packed[(size_t)y * pitch + x] = v;
-}
-
-hipError_t dvo_launch_sobel_pack(const uint8_t* gray, int w, int h, uint32_t* packed, int pitch, hipStream_t s)
-{
-    dim3 grid((w + 63) / 64, (h + 3) / 4);
-    hipLaunchKernelGGL(k_sobel_pack, grid, dim3(DVO_BLOCK), 0, s, gray, w, h, packed, pitch);
-    return hipGetLastError();
 }
 
 __global__ __launch_bounds__(DVO_BLOCK) void k_unpack(const uint32_t* __restrict__ packed, int w, int h, int pitch,
@@ -169,26 +105,62 @@ __global__ __launch_bounds__(DVO_BLOCK) void k_batch_copy_level0(const DvoBatchI
     }
 }
 
-template <typename T, bool DEPTH>
+// 4 output pixels per lane; gray (u8) and depth (u16) of one level in the same launch.  Fast path: one 8-byte
+// (u8) / 16-byte (u16) load per source row + the left neighbour; any odd geometry falls back to clamped scalar loads.
+template <typename T>
+__device__ __forceinline__ void median_down4(const T* __restrict__ src, int sw, int sh, T* __restrict__ dst, int dw,
+                                             int x4, int y)
+{
+    const int cy = 2 * y, ym = max(cy - 1, 0), yp = min(cy + 1, sh - 1);
+    const T* rows[3] = {src + (size_t)ym * sw, src + (size_t)cy * sw, src + (size_t)yp * sw};
+    unsigned c[3][9];
+    const int sx = 2 * x4;
+    const bool fast = (sw % 8 == 0) && (sx + 8 <= sw);
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        c[r][0] = rows[r][max(sx - 1, 0)];
+        if (fast) {
+            if (sizeof(T) == 1) {
+                const uint2 v = *reinterpret_cast<const uint2*>(rows[r] + sx);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) { c[r][1 + k] = (v.x >> (8 * k)) & 0xffu; c[r][5 + k] = (v.y >> (8 * k)) & 0xffu; }
+            } else {
+                const uint4 v = *reinterpret_cast<const uint4*>(rows[r] + sx);
+                c[r][1] = v.x & 0xffffu; c[r][2] = v.x >> 16; c[r][3] = v.y & 0xffffu; c[r][4] = v.y >> 16;
+                c[r][5] = v.z & 0xffffu; c[r][6] = v.z >> 16; c[r][7] = v.w & 0xffffu; c[r][8] = v.w >> 16;
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) c[r][1 + k] = rows[r][min(sx + k, sw - 1)];
+        }
+    }
+    unsigned m[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+        m[i] = median9(c[0][2 * i], c[0][2 * i + 1], c[0][2 * i + 2], c[1][2 * i], c[1][2 * i + 1], c[1][2 * i + 2],
+                       c[2][2 * i], c[2][2 * i + 1], c[2][2 * i + 2]);
+    T* out = dst + (size_t)y * dw + x4;
+    if ((dw % 4 == 0) && (x4 + 4 <= dw)) {
+        if (sizeof(T) == 1) *reinterpret_cast<uint32_t*>(out) = m[0] | (m[1] << 8) | (m[2] << 16) | (m[3] << 24);
+        else *reinterpret_cast<uint2*>(out) = make_uint2(m[0] | (m[1] << 16), m[2] | (m[3] << 16));
+    } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) if (x4 + i < dw) out[i] = (T)m[i];
+    }
+}
+
 __global__ __launch_bounds__(DVO_BLOCK) void k_batch_median_down(const DvoBatchIngestParams p, int level)
 {
     const int f = blockIdx.z;
     uint8_t* slot = p.slots + (size_t)p.slot_ids[f] * p.slot_stride;
     const DvoLevelGeom& gs = p.g[level - 1];
     const DvoLevelGeom& gd = p.g[level];
-    const T* src = reinterpret_cast<const T*>(slot + (DEPTH ? gs.off_depth : gs.off_gray));
-    T* dst = reinterpret_cast<T*>(slot + (DEPTH ? gd.off_depth : gd.off_gray));
-    const int sw = gs.w, sh = gs.h, dw = gd.w, dh = gd.h;
-    int x = blockIdx.x * 64 + (threadIdx.x & 63);
-    int y = blockIdx.y * 4 + (threadIdx.x >> 6);
-    if (x >= dw || y >= dh) return;
-    int cx = 2 * x, cy = 2 * y;
-    int xm = max(cx - 1, 0), xp = min(cx + 1, sw - 1);
-    int ym = max(cy - 1, 0), yp = min(cy + 1, sh - 1);
-    const T* r0 = src + (size_t)ym * sw;
-    const T* r1 = src + (size_t)cy * sw;
-    const T* r2 = src + (size_t)yp * sw;
-    dst[(size_t)y * dw + x] = (T)median9(r0[xm], r0[cx], r0[xp], r1[xm], r1[cx], r1[xp], r2[xm], r2[cx], r2[xp]);
+    const int x4 = (blockIdx.x * 64 + (threadIdx.x & 63)) * 4;
+    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x4 >= gd.w || y >= gd.h) return;
+    median_down4<uint8_t>(slot + gs.off_gray, gs.w, gs.h, slot + gd.off_gray, gd.w, x4, y);
+    median_down4<uint16_t>(reinterpret_cast<const uint16_t*>(slot + gs.off_depth), gs.w, gs.h,
+                           reinterpret_cast<uint16_t*>(slot + gd.off_depth), gd.w, x4, y);
 }
 
 __global__ __launch_bounds__(DVO_BLOCK) void k_batch_sobel_pack(const DvoBatchIngestParams p, int level)
@@ -199,20 +171,39 @@ __global__ __launch_bounds__(DVO_BLOCK) void k_batch_sobel_pack(const DvoBatchIn
     const uint8_t* gray = slot + g.off_gray;
     uint32_t* packed = reinterpret_cast<uint32_t*>(slot + g.off_packed);
     const int w = g.w, h = g.h;
-    int x = blockIdx.x * 64 + (threadIdx.x & 63);
-    int y = blockIdx.y * 4 + (threadIdx.x >> 6);
-    if (x >= w || y >= h) return;
-    int xm = max(x - 1, 0), xp = min(x + 1, w - 1);
-    int ym = max(y - 1, 0), yp = min(y + 1, h - 1);
-    const uint8_t* r0 = gray + (size_t)ym * w;
-    const uint8_t* r1 = gray + (size_t)y * w;
-    const uint8_t* r2 = gray + (size_t)yp * w;
-    int p00 = r0[xm], p01 = r0[x], p02 = r0[xp];
-    int p10 = r1[xm], p11 = r1[x], p12 = r1[xp];
-    int p20 = r2[xm], p21 = r2[x], p22 = r2[xp];
-    int gx = (p02 + 2 * p12 + p22) - (p00 + 2 * p10 + p20);
-    int gy = (p20 + 2 * p21 + p22) - (p00 + 2 * p01 + p02);
-    packed[(size_t)y * g.pitch + x] = (uint32_t)p11 | (((uint32_t)gx & 0xfffu) << 8) | (((uint32_t)gy & 0xfffu) << 20);
+    const int x4 = (blockIdx.x * 64 + (threadIdx.x & 63)) * 4;
+    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x4 >= w || y >= h) return;
+    // BORDER_REFLECT with radius 1 == index clamp
+    const int ym = max(y - 1, 0), yp = min(y + 1, h - 1);
+    const uint8_t* rows[3] = {gray + (size_t)ym * w, gray + (size_t)y * w, gray + (size_t)yp * w};
+    int c[3][6];
+    const bool fast = (w % 4 == 0) && (x4 + 4 <= w);
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        c[r][0] = rows[r][max(x4 - 1, 0)];
+        if (fast) {
+            const uint32_t v = *reinterpret_cast<const uint32_t*>(rows[r] + x4);
+            c[r][1] = v & 0xffu; c[r][2] = (v >> 8) & 0xffu; c[r][3] = (v >> 16) & 0xffu; c[r][4] = v >> 24;
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) c[r][1 + k] = rows[r][min(x4 + k, w - 1)];
+        }
+        c[r][5] = rows[r][min(x4 + 4, w - 1)];
+    }
+    uint32_t out[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int gx = (c[0][i + 2] + 2 * c[1][i + 2] + c[2][i + 2]) - (c[0][i] + 2 * c[1][i] + c[2][i]);
+        const int gy = (c[2][i] + 2 * c[2][i + 1] + c[2][i + 2]) - (c[0][i] + 2 * c[0][i + 1] + c[0][i + 2]);
+        out[i] = (uint32_t)c[1][i + 1] | (((uint32_t)gx & 0xfffu) << 8) | (((uint32_t)gy & 0xfffu) << 20);
+    }
+    uint32_t* dst = packed + (size_t)y * g.pitch + x4;
+    if (x4 + 4 <= w) *reinterpret_cast<uint4*>(dst) = make_uint4(out[0], out[1], out[2], out[3]);
+    else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) if (x4 + i < w) dst[i] = out[i];
+    }
 }
 
 hipError_t dvo_launch_batch_ingest(const DvoBatchIngestParams& p, hipStream_t s)
@@ -223,11 +214,8 @@ hipError_t dvo_launch_batch_ingest(const DvoBatchIngestParams& p, hipStream_t s)
         hipLaunchKernelGGL(k_batch_copy_level0, grid, dim3(DVO_BLOCK), 0, s, p);
     }
     for (int l = 0; l < p.levels; ++l) {
-        dim3 grid((p.g[l].w + 63) / 64, (p.g[l].h + 3) / 4, nf);
-        if (l > 0) {
-            hipLaunchKernelGGL((k_batch_median_down<uint8_t, false>), grid, dim3(DVO_BLOCK), 0, s, p, l);
-            hipLaunchKernelGGL((k_batch_median_down<uint16_t, true>), grid, dim3(DVO_BLOCK), 0, s, p, l);
-        }
+        dim3 grid((p.g[l].w + 255) / 256, (p.g[l].h + 3) / 4, nf);
+        if (l > 0) hipLaunchKernelGGL(k_batch_median_down, grid, dim3(DVO_BLOCK), 0, s, p, l);
         hipLaunchKernelGGL(k_batch_sobel_pack, grid, dim3(DVO_BLOCK), 0, s, p, l);
     }
     return hipGetLastError();
