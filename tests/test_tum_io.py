@@ -1,0 +1,66 @@
+"""TUM RGB-D I/O around the hot path (row f1): association, trajectory writer, ATE/RPE.  CPU only."""
+import numpy as np
+import pytest
+
+from dvo_amd import tum
+
+
+def _write_png(path, arr):
+    from PIL import Image
+    Image.fromarray(arr).save(path)
+
+
+def test_association_follows_reference_rules(tmp_path):
+    (tmp_path / "rgb").mkdir()
+    (tmp_path / "depth").mkdir()
+    t_rgb = [1.00, 1.033, 1.066, 1.10, 1.133]
+    t_d = [1.01, 1.07, 1.105, 1.20]              # rgb 1.00 and 1.033 both claim depth 1.01 -> the first is kept
+    rng = np.random.default_rng(0)
+    with (tmp_path / "rgb.txt").open("w") as fp:
+        fp.write("# color images\n# timestamp filename\n")
+        for t in t_rgb:
+            _write_png(tmp_path / "rgb" / ("%.3f.png" % t), rng.integers(0, 255, (6, 8, 3), dtype=np.uint8))
+            fp.write("%.3f rgb/%.3f.png\n" % (t, t))
+    with (tmp_path / "depth.txt").open("w") as fp:
+        fp.write("# depth maps\n")
+        for t in t_d:
+            _write_png(tmp_path / "depth" / ("%.3f.png" % t), rng.integers(0, 30000, (6, 8)).astype(np.uint16))
+            fp.write("%.3f depth/%.3f.png\n" % (t, t))
+    with (tmp_path / "groundtruth.txt").open("w") as fp:
+        fp.write("# timestamp tx ty tz qx qy qz qw\n")
+        for i, t in enumerate(np.arange(0.9, 1.3, 0.01)):
+            fp.write("%.2f %f 0 0 0 0 0 1\n" % (t, 0.1 * i))
+    seq = tum.load_tum_sequence(tmp_path)
+    # rgb 1.133 is also closest to depth 1.105 (already taken by rgb 1.100) -> dropped; depth 1.200 stays unused
+    assert [p[-9:] for p in seq.rgb_paths] == ["1.000.png", "1.066.png", "1.100.png"]
+    assert [p[-9:] for p in seq.depth_paths] == ["1.010.png", "1.070.png", "1.105.png"]
+    np.testing.assert_allclose(seq.timestamps, [(1.0 + 1.01) / 2, (1.066 + 1.07) / 2, (1.1 + 1.105) / 2])
+    np.testing.assert_allclose(seq.gt_timestamps, [1.00, 1.07, 1.10], atol=1e-9)             # nearest GT stamp
+    assert seq.gt_T_wc.shape == (3, 4, 4) and abs(seq.gt_T_wc[1, 0, 3] - 0.1 * 17) < 1e-6
+    bgr, depth = tum.read_frame(seq.rgb_paths[0], seq.depth_paths[0])
+    assert bgr.shape == (6, 8, 3) and bgr.dtype == np.uint8 and depth.dtype == np.uint16 and depth.shape == (6, 8)
+    assert len(tum.load_tum_sequence(tmp_path, size=2)) == 2
+    with pytest.raises(FileNotFoundError):
+        tum.load_tum_sequence(tmp_path / "rgb")
+
+
+def test_trajectory_round_trip_and_errors(tmp_path):
+    rng = np.random.default_rng(1)
+    n = 12
+    T = np.tile(np.eye(4), (n, 1, 1))
+    for i in range(n):
+        q = rng.normal(size=4)
+        T[i, :3, :3] = tum.quat_xyzw_to_matrix(q / np.linalg.norm(q))
+        T[i, :3, 3] = rng.normal(size=3)
+        np.testing.assert_allclose(tum.quat_xyzw_to_matrix(tum.matrix_to_quat_xyzw(T[i, :3, :3])), T[i, :3, :3], atol=1e-12)
+    stamps = 1305031102.0 + np.arange(n) / 30
+    tum.write_tum_trajectory(tmp_path / "traj.txt", stamps, T)
+    s2, T2 = tum.read_tum_trajectory(tmp_path / "traj.txt")
+    np.testing.assert_allclose(s2, stamps)
+    np.testing.assert_allclose(T2, T, atol=1e-12)
+    ev = tum.evaluate(T, T)
+    assert ev["ate_rmse_m"] < 1e-12 and ev["rpe_trans_rmse_m"] < 1e-12 and ev["rpe_rot_rmse_rad"] < 1e-6
+    T3 = T.copy()
+    T3[5:, :3, 3] += np.array([0.02, 0.0, 0.0])       # one bad relative step
+    rt, rr = tum.relative_pose_error(T3, T)
+    assert abs(rt - 0.02 / np.sqrt(n - 1)) < 1e-9 and rr < 1e-6
