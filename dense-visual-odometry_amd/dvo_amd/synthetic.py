@@ -70,16 +70,26 @@ def make_stream(n_frames: int, width: int = 640, height: int = 480, seed: int = 
                           torch.arange(width, dtype=torch.float64, device=dev), indexing="ij")
     rays = torch.stack([(u - K[0, 2]) / K[0, 0], (v - K[1, 2]) / K[1, 1], torch.ones_like(u)], dim=0).reshape(3, -1)
 
-    # smooth trajectory: constant-magnitude twist whose direction drifts slowly
-    d_t = rng.normal(size=3)
-    d_r = rng.normal(size=3)
-    R = np.eye(3)
-    t = np.zeros(3)
+    # bounded smooth trajectory (the scene stays in view and in depth range for any stream length): position and
+    # rotation vector are sums of sinusoids whose per-frame steps are ~step_trans metres and ~step_rot_deg degrees
+    amp_t = np.array([0.25, 0.15, 0.10])
+    amp_r = np.array([0.06, 0.06, 0.04])
+    per_t = 2 * np.pi * amp_t / (step_trans / np.sqrt(3)) * rng.uniform(0.9, 1.1, 3)
+    per_r = 2 * np.pi * amp_r / (np.deg2rad(step_rot_deg) / np.sqrt(3)) * rng.uniform(0.9, 1.1, 3)
+    ph_t = rng.uniform(0, 2 * np.pi, 3)
+    ph_r = rng.uniform(0, 2 * np.pi, 3)
+
+    def pose_at(k):
+        tk = amp_t * (np.sin(2 * np.pi * k / per_t + ph_t) - np.sin(ph_t))
+        rk = amp_r * (np.sin(2 * np.pi * k / per_r + ph_r) - np.sin(ph_r))
+        return _rot(rk), tk
+
     grays, depths, poses = [], [], []
     z0 = 2.4
     b = max(1, int(round(16 * width / 640.0)))
     blob_params = [(1.0, 1.0, 0.3, 1.1, 1.0), (2.3, 1.7, 2.0, 0.4, 0.6)]
     for k in range(n_frames):
+        R, t = pose_at(k)
         T = np.eye(4)
         T[:3, :3], T[:3, 3] = R, t
         poses.append(T)
@@ -103,13 +113,6 @@ def make_stream(n_frames: int, width: int = 640, height: int = 480, seed: int = 
         depth[:b], depth[-b:], depth[:, :b], depth[:, -b:] = 0, 0, 0, 0
         grays.append(gray)
         depths.append(depth.to(torch.int16))            # bit pattern of the u16 value (max 22500 < 32768)
-        # advance the camera
-        d_t = d_t + 0.15 * rng.normal(size=3)
-        d_r = d_r + 0.15 * rng.normal(size=3)
-        dt = step_trans * d_t / np.linalg.norm(d_t)
-        dr = np.deg2rad(step_rot_deg) * d_r / np.linalg.norm(d_r)
-        t = t + R @ dt
-        R = R @ _rot(dr)
     gray_t = torch.stack(grays).contiguous()
     depth_t = torch.stack(depths).contiguous()
     out = dict(K=K.astype(np.float32), depth_scale=DEPTH_SCALE, T_wc=np.stack(poses))
