@@ -34,8 +34,8 @@ struct HostStage {          // pinned staging for the small per-call arrays
 }  // namespace
 
 struct SolveKey {
-    int n_pairs, w, h, levels, max_iterations, max_increased, variant, weight_mode, has_init, trace_cap;
-    double tolerance, weight_param;
+    int n_pairs, w, h, levels, max_iterations, max_increased, variant, weight_mode, has_init, trace_cap, has_last, pad;
+    double tolerance, weight_param, inv_sigma;
     const void* trace;
     const void* stream;
 };
@@ -74,6 +74,10 @@ struct dvo_ctx {
     float* d_dense = nullptr;            // dense writer outputs: r[npix] J[6 npix] uv[2 npix] + valid
     double* d_trace = nullptr;
     int trace_cap = 0;
+    double* d_prior = nullptr;           // [max_pairs][7] previous-pair transforms for the motion prior
+    double* h_prior = nullptr;
+    double prior_sigma = 0.0;            // <= 0: prior off
+    bool prior_has_last = false;
     HostStage hs;
     // profiling
     bool profiling = false;
@@ -370,6 +374,8 @@ int dvo_create(int device, int max_w, int max_h, int max_levels, int n_slots, in
     CREATE_TRY(hipMalloc((void**)&ctx->d_xi, np * 6 * sizeof(double)));
     CREATE_TRY(hipMalloc((void**)&ctx->d_iters, np * sizeof(int)));
     CREATE_TRY(hipMalloc((void**)&ctx->d_err, np * sizeof(double)));
+    CREATE_TRY(hipMalloc((void**)&ctx->d_prior, np * 7 * sizeof(double)));
+    CREATE_TRY(hipHostMalloc((void**)&ctx->h_prior, np * 7 * sizeof(double)));
     CREATE_TRY(hipMalloc((void**)&ctx->d_stage_img, (size_t)max_w * max_h * 5 + 256));
     CREATE_TRY(hipMalloc((void**)&ctx->d_dense, (size_t)max_w * max_h * (9 * sizeof(float) + 1) + 256));
     CREATE_TRY(hipHostMalloc((void**)&ctx->hs.prev, np * sizeof(int)));
@@ -403,9 +409,9 @@ void dvo_destroy(dvo_ctx* ctx)
     if (ctx->tm_a) (void)hipEventDestroy(ctx->tm_a);
     if (ctx->tm_b) (void)hipEventDestroy(ctx->tm_b);
     void* dev[] = {ctx->d_slots, ctx->d_prev, ctx->d_cur, ctx->d_T, ctx->d_Tinit, ctx->d_wparam, ctx->d_active, ctx->d_partials,
-                   ctx->d_out, ctx->d_state, ctx->d_xi, ctx->d_iters, ctx->d_err, ctx->d_stage_img, ctx->d_dense, ctx->d_trace, ctx->d_frame_slots};
+                   ctx->d_out, ctx->d_state, ctx->d_xi, ctx->d_iters, ctx->d_err, ctx->d_stage_img, ctx->d_dense, ctx->d_trace, ctx->d_frame_slots, ctx->d_prior};
     for (void* p : dev) if (p) (void)hipFree(p);
-    void* host[] = {ctx->hs.prev, ctx->hs.cur, ctx->hs.T, ctx->hs.wparam, ctx->hs.out, ctx->hs.xi, ctx->hs.iters, ctx->hs.err, ctx->h_frame_slots};
+    void* host[] = {ctx->hs.prev, ctx->hs.cur, ctx->hs.T, ctx->hs.wparam, ctx->hs.out, ctx->hs.xi, ctx->hs.iters, ctx->hs.err, ctx->h_frame_slots, ctx->h_prior};
     for (void* p : host) if (p) (void)hipHostFree(p);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
@@ -713,7 +719,8 @@ static int record_solve(dvo_ctx* ctx, const SolveKey& k, const float* d_init)
     const double tolerance = k.tolerance, weight_param = k.weight_param;
     int rc;
     const double lambda0 = 1.0 / 25.0;                      // TDistributionWeighter: initial_sigma = 5 (t_weighter.py:11-15)
-    HIP_TRY(ctx, dvo_launch_init_state(ctx->d_state, ctx->d_T, d_init, n_pairs, lambda0, ctx->stream));
+    HIP_TRY(ctx, dvo_launch_init_state(ctx->d_state, ctx->d_T, d_init, n_pairs, lambda0,
+                                       (k.inv_sigma > 0.0 && k.has_last) ? ctx->d_prior : nullptr, ctx->stream));
     for (int level = levels - 1; level >= 0; --level) {
         DvoReduceParams p;
         rc = fill_reduce_params(ctx, level, n_pairs, w, h, &p);
@@ -731,6 +738,7 @@ static int record_solve(dvo_ctx* ctx, const SolveKey& k, const float* d_init)
         sp.max_increased = max_increased_steps_allowed;
         sp.weight_mode = weight_mode;
         sp.weight_param = weight_param;
+        sp.inv_sigma = k.inv_sigma;
         sp.trace = ctx->d_trace;
         sp.trace_stride = DVO_STRIDE + 18;
         sp.trace_cap = ctx->trace_cap;
@@ -785,6 +793,8 @@ int dvo_solve_batch_enqueue(dvo_ctx* ctx, int n_pairs, const int* prev_slot, con
     key.max_increased = max_increased_steps_allowed; key.variant = variant; key.weight_mode = weight_mode;
     key.tolerance = tolerance; key.weight_param = weight_param; key.has_init = T_init ? 1 : 0;
     key.trace = ctx->d_trace; key.trace_cap = ctx->trace_cap; key.stream = ctx->stream;
+    key.inv_sigma = (ctx->prior_sigma > 0.0) ? 1.0 / ctx->prior_sigma : 0.0;
+    key.has_last = ctx->prior_has_last ? 1 : 0;
     const bool use_graph = ctx->graphs_enabled && !ctx->profiling;
     if (use_graph) {
         for (auto& g : ctx->graphs)
@@ -835,6 +845,23 @@ int dvo_solve_batch(dvo_ctx* ctx, int n_pairs, const int* prev_slot, const int* 
                                      max_increased_steps_allowed, variant, weight_mode, weight_param, T_init);
     if (rc) return rc;
     return dvo_solve_batch_fetch(ctx, n_pairs, T_out, xi_out, iters_out, err_out);
+}
+
+int dvo_set_prior(dvo_ctx* ctx, double sigma, const double* last_qt, int n_pairs)
+{
+    if (!ctx) return DVO_ERR_INVALID_ARG;
+    if (!(sigma > 0.0)) { ctx->prior_sigma = 0.0; ctx->prior_has_last = false; return DVO_OK; }
+    ctx->prior_sigma = sigma;
+    ctx->prior_has_last = false;
+    if (last_qt) {
+        if (n_pairs <= 0 || n_pairs > ctx->max_pairs) return fail(ctx, DVO_ERR_INVALID_ARG, "n_pairs %d outside [1,%d]", n_pairs, ctx->max_pairs);
+        HIP_TRY(ctx, hipSetDevice(ctx->device));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));          // h_prior may still be in flight
+        memcpy(ctx->h_prior, last_qt, (size_t)n_pairs * 7 * sizeof(double));
+        HIP_TRY(ctx, hipMemcpyAsync(ctx->d_prior, ctx->h_prior, (size_t)n_pairs * 7 * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+        ctx->prior_has_last = true;
+    }
+    return DVO_OK;
 }
 
 int dvo_trace_enable(dvo_ctx* ctx, int max_iterations_traced)

@@ -70,6 +70,8 @@ struct DvoPairState {
     double err_prev;    // last accepted error (base_robust_dvo.py:158)
     double err_last;    // error of the last evaluated iteration
     double lambda;      // student-t: current lambda; huber: previous sigma (<=0: none yet)
+    double lq[4], lt[3];   // motion prior: previous pair's transform (quaternion wxyz, translation)
+    double oq[4], ot[3];   // motion prior: `old` of base_robust_dvo.py:154,:217-218
     int increased;      // err_increased_count (:159)
     int active;         // 1 while this level is still iterating for this pair
     int iters;          // total GN iterations evaluated
@@ -88,6 +90,7 @@ struct DvoSolveParams {
     int max_increased;
     int weight_mode;
     double weight_param;        // huber: k multiplier
+    double inv_sigma;           // motion prior 1/sigma (base_robust_dvo.py:69-71), 0 = off
     int phase;                  // 0: normal-equation iteration; 1/2: student-t scale passes
     double* trace;              // optional [n_pairs][max_trace][DVO_STRIDE+8] per-iteration records, or null
     int trace_stride, trace_cap;
@@ -111,7 +114,8 @@ hipError_t dvo_launch_unpack(const uint32_t* packed, int w, int h, int pitch, in
 hipError_t dvo_launch_reduce(const DvoReduceParams& p, int variant, int weight_mode, int scale_pass, hipStream_t s);
 hipError_t dvo_launch_sum_partials(const double* partials, int blocks_per_pair, int n_pairs, double* out, hipStream_t s);
 hipError_t dvo_launch_dense(const DvoDenseParams& p, int variant, hipStream_t s);
-hipError_t dvo_launch_init_state(DvoPairState* st, float* T, const float* T_init, int n_pairs, double lambda0, hipStream_t s);
+hipError_t dvo_launch_init_state(DvoPairState* st, float* T, const float* T_init, int n_pairs, double lambda0,
+                                 const double* prior_qt, hipStream_t s);
 hipError_t dvo_launch_level_begin(DvoPairState* st, int* active, double* wparam, int n_pairs, int weight_mode,
                                   double lambda0, hipStream_t s);
 hipError_t dvo_launch_solve(const DvoSolveParams& p, hipStream_t s);

@@ -860,7 +860,8 @@ __device__ __forceinline__ void solve6(const double* hu, const double* b, double
     solve6_pinv(hu, b, dmax, x);
 }
 
-__global__ void k_init_state(DvoPairState* st, float* T, const float* T_init, int n_pairs, double lambda0)
+__global__ void k_init_state(DvoPairState* st, float* T, const float* T_init, int n_pairs, double lambda0,
+                             const double* prior_qt)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_pairs) return;
@@ -889,6 +890,14 @@ __global__ void k_init_state(DvoPairState* st, float* T, const float* T_init, in
         }
         s.t[0] = M[3]; s.t[1] = M[7]; s.t[2] = M[11];
     }
+    // motion prior (base_robust_dvo.py:154): `old` restarts at every level from the previous pair's transform
+    s.lq[0] = 1; s.lq[1] = s.lq[2] = s.lq[3] = 0; s.lt[0] = s.lt[1] = s.lt[2] = 0;
+    if (prior_qt != nullptr) {
+        for (int k = 0; k < 4; ++k) s.lq[k] = prior_qt[(size_t)i * 7 + k];
+        for (int k = 0; k < 3; ++k) s.lt[k] = prior_qt[(size_t)i * 7 + 4 + k];
+    }
+    for (int k = 0; k < 4; ++k) s.oq[k] = s.lq[k];
+    for (int k = 0; k < 3; ++k) s.ot[k] = s.lt[k];
     s.err_prev = DVO_FLT_MAX;
     s.err_last = __builtin_nan("");
     s.lambda = -1.0;
@@ -901,9 +910,10 @@ __global__ void k_init_state(DvoPairState* st, float* T, const float* T_init, in
     (void)lambda0;
 }
 
-hipError_t dvo_launch_init_state(DvoPairState* st, float* T, const float* T_init, int n_pairs, double lambda0, hipStream_t s)
+hipError_t dvo_launch_init_state(DvoPairState* st, float* T, const float* T_init, int n_pairs, double lambda0,
+                                 const double* prior_qt, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_init_state, dim3((n_pairs + 63) / 64), dim3(64), 0, s, st, T, T_init, n_pairs, lambda0);
+    hipLaunchKernelGGL(k_init_state, dim3((n_pairs + 63) / 64), dim3(64), 0, s, st, T, T_init, n_pairs, lambda0, prior_qt);
     return hipGetLastError();
 }
 
@@ -916,6 +926,8 @@ __global__ void k_level_begin(DvoPairState* st, int* active, double* wparam, int
     st[i].increased = 0;
     st[i].active = 1;
     active[i] = 1;
+    for (int k = 0; k < 4; ++k) st[i].oq[k] = st[i].lq[k];          // old = last_estimated_transform.copy()  (:154)
+    for (int k = 0; k < 3; ++k) st[i].ot[k] = st[i].lt[k];
     if (weight_mode == 1) wparam[i] = lambda0;                                     // t_weighter.py:23
     if (weight_mode == 2) wparam[i] = (st[i].lambda > 0.0) ? st[i].lambda : DVO_FLT_MAX;   // no scale yet: w = 1
 }
@@ -953,6 +965,15 @@ __global__ __launch_bounds__(DVO_BLOCK) void k_solve(const DvoSolveParams p)
     double err = (n > 0.0) ? (double)(float)(rec[27] / n) : __builtin_nan("");      // np.mean(...) float32, :177/:184
     double bneg[6], inc[6];
     for (int i = 0; i < 6; ++i) bneg[i] = -rec[21 + i];                                // b = -J^T W r, :188
+    if (p.inv_sigma > 0.0) {
+        // H += I/sigma ; b += (I/sigma) log(old) ; err += 0.5 sigma |log(old)|        (:190-194)
+        double xo[6];
+        se3_log(st.oq, st.ot, xo);
+        const int dg[6] = {0, 6, 11, 15, 18, 20};
+        double nrm = 0.0;
+        for (int i = 0; i < 6; ++i) { rec[dg[i]] += p.inv_sigma; bneg[i] += p.inv_sigma * xo[i]; nrm += xo[i] * xo[i]; }
+        err += 0.5 * (1.0 / p.inv_sigma) * sqrt(nrm);
+    }
     solve6(rec, bneg, inc);
     st.iters += 1;
     st.err_last = err;
@@ -976,6 +997,14 @@ __global__ __launch_bounds__(DVO_BLOCK) void k_solve(const DvoSolveParams p)
             st.err_prev = err;
             st.increased = 0;
             se3_write_T(st.q, st.t, p.T + (size_t)pair * 12);
+            if (p.inv_sigma > 0.0) {                                                    // old = inc.inverse() * old  (:217-218)
+                double qv[4] = {qi[0], -qi[1], -qi[2], -qi[3]}, Ri[9], tv[3], qo[4], to[3];
+                quat_to_R(qv, Ri);
+                for (int a = 0; a < 3; ++a) tv[a] = -(Ri[3 * a] * ti[0] + Ri[3 * a + 1] * ti[1] + Ri[3 * a + 2] * ti[2]);
+                se3_mul(qv, tv, st.oq, st.ot, qo, to);
+                for (int a = 0; a < 4; ++a) st.oq[a] = qo[a];
+                for (int a = 0; a < 3; ++a) st.ot[a] = to[a];
+            }
         } else {
             st.increased += 1;                                                          // :222 (no rollback, quirk Q8)
         }

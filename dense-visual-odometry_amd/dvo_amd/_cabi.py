@@ -60,6 +60,7 @@ SIGNATURES = {
     "dvo_solve_batch_enqueue": (C.c_int, [_ctx, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_double,
                                           C.c_int, C.c_int, C.c_int, C.c_double, C.c_void_p]),
     "dvo_solve_batch_fetch": (C.c_int, [_ctx, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "dvo_set_prior": (C.c_int, [_ctx, C.c_double, C.c_void_p, C.c_int]),
     "dvo_trace_enable": (C.c_int, [_ctx, C.c_int]),
     "dvo_trace_read": (C.c_int, [_ctx, C.c_int, C.c_void_p]),
     "dvo_profile_enable": (C.c_int, [_ctx, C.c_int]),
@@ -297,6 +298,14 @@ class HipContext:
         err = np.empty(n, dtype=np.float64)
         self._check(self._lib.dvo_solve_batch_fetch(self._h, n, _ptr(T), _ptr(xi), _ptr(iters), _ptr(err)))
         return dict(T=T, xi=xi, iters=iters, err=err)
+
+    def set_prior(self, sigma: Optional[float], last_qt: Optional[np.ndarray] = None):
+        """Motion prior for the following solve_batch calls (sigma None/<=0: off). last_qt: (n,7) qw qx qy qz tx ty tz."""
+        if sigma is None or not sigma > 0:
+            self._check(self._lib.dvo_set_prior(self._h, 0.0, None, 0))
+            return
+        q = None if last_qt is None else _as(last_qt, np.float64).reshape(-1, 7)
+        self._check(self._lib.dvo_set_prior(self._h, float(sigma), _ptr(q), 0 if q is None else q.shape[0]))
 
     def trace_enable(self, cap: int):
         self._check(self._lib.dvo_trace_enable(self._h, cap))

@@ -12,7 +12,8 @@ Differences a maintainer should know about (all switchable or inert for the refe
     (`solver="host"`, default) — or the whole loop runs on the device (`solver="device"`);
   * `compute_residuals_and_jacobian` keeps the reference's return contract through the dense debug kernel;
   * the previous frame's pyramid stays resident on the device instead of being rebuilt every step (quirk Q9);
-  * the sigma motion prior (base_robust_dvo.py:190-194) is not on this path: `sigma` must be None.
+  * with `sigma` set (motion prior, base_robust_dvo.py:190-194) consecutive pairs are coupled through the last
+    estimated transform; the per-pair API below handles that, the batched front end does not apply a prior.
 """
 from __future__ import annotations
 
@@ -70,8 +71,6 @@ class RobustDVOHIP:
                  height: int = 480, width: int = 640, device: int = 0, solver: str = "host",
                  weighting: Optional[str] = None, huber_k: float = 1.345, max_distance: float = 5.0,
                  mutate_depth: bool = True):
-        if sigma is not None:
-            raise NotImplementedError("the sigma motion prior (base_robust_dvo.py:190-194) is outside the HIP hot path")
         if levels < 1:
             raise ValueError("Expected 'levels' to be >= 1, got '{}' instead".format(levels))
         if solver not in ("host", "device"):
@@ -84,7 +83,7 @@ class RobustDVOHIP:
         self._max_distance = max_distance
         self._levels = levels
         self._max_increased_steps_allowed = max_increased_steps_allowed
-        self._sigma = None
+        self._sigma = sigma                 # motion prior (base_robust_dvo.py:69-71); None = off (reference default)
         self._tolerance = tolerance
         self._max_iter = max_iterations
         self._approximate_image2_gradients = approximate_image2_gradient
@@ -269,12 +268,20 @@ class RobustDVOHIP:
         self.last_iterations = 0
         self._huber_sigma = None
         for level in range(self._levels - 1, -1, -1):
+            old = None
+            if (self._sigma is not None) and (self._last_estimated_transform is not None):
+                old = self._last_estimated_transform.copy()                       # base_robust_dvo.py:154
             err_prev = np.finfo("float32").max
             err_increased_count = 0
             self._setup(level=level)
             for i in range(self._max_iter):
                 H, b, err, n = self.compute_normal_equations(estimate=estimate, level=level)
                 self.last_iterations += 1
+                if old is not None:                                               # :190-194
+                    xo = old.log().astype(np.float64).reshape(6)
+                    H = H + np.eye(6) / self._sigma
+                    b = b + xo / self._sigma
+                    err += 0.5 * self._sigma * float(np.linalg.norm(xo))
                 if np.all(np.isfinite(H)) and np.all(np.isfinite(b)):
                     inc_xi = scipy.linalg.lstsq(H, b.reshape(6, 1), lapack_driver="gelsy", check_finite=False)[0]
                 else:
@@ -288,6 +295,8 @@ class RobustDVOHIP:
                 if err_diff < 0.0:
                     estimate = inc * estimate
                     err_prev = err
+                    if old is not None:
+                        old = inc.inverse() * old                                 # :217-218
                     err_increased_count = 0
                 else:
                     err_increased_count += 1
@@ -305,6 +314,13 @@ class RobustDVOHIP:
         if not np.allclose(init_guess.exp(), np.eye(4)):
             T0 = init_guess.exp()[None, :3, :]
         wmode = _WEIGHTS[self._weighting]
+        if self._sigma is not None and self._last_estimated_transform is not None:
+            last = self._last_estimated_transform
+            qt = np.concatenate([np.asarray(last.so3.quat, dtype=np.float64).reshape(4),
+                                 np.asarray(last.tvec, dtype=np.float64).reshape(3)])[None]
+            self._ctx.set_prior(self._sigma, qt)
+        else:
+            self._ctx.set_prior(None)
         res = self._ctx.solve_batch([self._prev_slot], [self._cur_slot], self._levels, self._max_iter,
                                     self._tolerance, self._max_increased_steps_allowed, self._variant, wmode,
                                     self._huber_k, T0)

@@ -147,6 +147,13 @@ int dvo_solve_batch_enqueue(dvo_ctx* ctx, int n_pairs, const int* prev_slot, con
                             int weight_mode, double weight_param, const float* T_init);
 int dvo_solve_batch_fetch(dvo_ctx* ctx, int n_pairs, float* T_out, double* xi_out, int* iters_out, double* err_out);
 
+/* Motion prior of the reference (sigma, base_robust_dvo.py:69-71,:154,:190-194,:217-218) for subsequent
+ * dvo_solve_batch calls: H += I/sigma, b += (I/sigma) log(old), err += 0.5 sigma |log(old)|, old <- inc^-1 old, with
+ * `old` restarting at every level from the previous pair's transform last_qt[pair] = (qw qx qy qz tx ty tz), or the
+ * identity when last_qt is NULL.  sigma <= 0 switches the prior off.  The prior couples consecutive pairs of a
+ * sequence, so with it a sequence is processed pair after pair (SURVEY 8e "when not"). */
+int dvo_set_prior(dvo_ctx* ctx, double sigma, const double* last_qt, int n_pairs);
+
 /* Per-iteration trace of dvo_solve_batch (tests / debugging): enable with the number of iterations to keep
  * per pair (0 disables).  Each record is DVO_TRACE_STRIDE doubles: the normal-equation record [0..31], the
  * solved increment xi [32..37] and the 3x4 pose the iteration was evaluated at [38..49]. */

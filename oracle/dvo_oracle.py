@@ -537,8 +537,10 @@ class IterRecord:
 def gauss_newton(gray_prev, depth_prev, gray_cur, K, depth_scale, levels: int, max_iterations: int = 100,
                  tolerance: float = 1e-6, max_increased_steps_allowed: int = 0, use_weighter: bool = False,
                  variant: str = VARIANT_V1, accumulate: str = "fp64", weighting: Optional[str] = None,
-                 huber_k: float = 1.345, init: Optional[Pose] = None, record: Optional[list] = None) -> Pose:
-    """BaseRobustDVO._step, base_robust_dvo.py:137-236 (sigma prior off, its default)."""
+                 huber_k: float = 1.345, init: Optional[Pose] = None, record: Optional[list] = None,
+                 sigma: Optional[float] = None, last_transform: Optional[Pose] = None) -> Pose:
+    """BaseRobustDVO._step, base_robust_dvo.py:137-236.  `sigma` / `last_transform`: the motion prior of
+    :69-71, :154, :190-194, :217-218 (`last_transform` = self._last_estimated_transform)."""
     gp = build_pyramid(gray_prev, levels)
     dp = build_pyramid(depth_prev, levels)
     gc = build_pyramid(gray_cur, levels)
@@ -550,6 +552,9 @@ def gauss_newton(gray_prev, depth_prev, gray_cur, K, depth_scale, levels: int, m
         lv = PairLevel(gp[level], dp[level], gc[level], level_intrinsics(K, level), depth_scale)
         err_prev = float(np.finfo("float32").max)
         increased = 0
+        old = None
+        if sigma is not None and last_transform is not None:
+            old = Pose(np.array(last_transform.quat), np.array(last_transform.tvec))      # :154
         for i in range(max_iterations):
             T = estimate.matrix()
             r, J, _, _ = residuals_and_jacobian(lv, T, variant)
@@ -568,6 +573,11 @@ def gauss_newton(gray_prev, depth_prev, gray_cur, K, depth_scale, levels: int, m
                 r64 = r.astype(np.float32).astype(np.float64).reshape(-1)
                 sigma_prev = math.sqrt(float(np.sum(r64 * r64)) / n) if n else None
             err = float(np.float32(s / n)) if n else float("nan")             # :177 / :184 (float32 mean)
+            if old is not None:                                               # :190-194
+                xo = old.log().astype(np.float64)
+                H = np.array(H, dtype=np.float64) + np.eye(6) / sigma
+                b = np.array(b, dtype=np.float64).reshape(6) + xo / sigma
+                err += 0.5 * sigma * float(np.linalg.norm(xo))
             inc_xi = solve_increment(H, b)
             if record is not None:
                 record.append(IterRecord(level, T, n, np.array(H), np.array(b).reshape(6), np.array(inc_xi), err, s))
@@ -578,6 +588,8 @@ def gauss_newton(gray_prev, depth_prev, gray_cur, K, depth_scale, levels: int, m
             if diff < 0.0:                                                    # :212
                 estimate = inc.mul(estimate)
                 err_prev = err
+                if old is not None:
+                    old = inc.inverse().mul(old)                              # :217-218
                 increased = 0
             else:
                 increased += 1

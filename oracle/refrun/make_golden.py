@@ -36,7 +36,7 @@ vectorised form accumulates in float64 as numba's type inference does, the inter
 accumulates in float32).
 
 Outputs (tests/golden/): frames.npz (inputs), pairs_l4.npz, single_l1.npz, weighted_l4.npz,
-approx_l4.npz, dense_rj.npz, tiny10.npz, sequence.npz, lie.npz, meta.json.
+approx_l4.npz, sigma_l4.npz, dense_rj.npz, tiny10.npz, sequence.npz, lie.npz, meta.json.
 """
 import json
 import sys
@@ -258,10 +258,44 @@ def run_pair(cam, prev, cur, keep_dense=False, **cfg):
     return tf, rec, dvo
 
 
+def sigma_case(cam, frames, sigma=1e-13, n_frames=4):
+    """Motion prior (base_robust_dvo.py:190-194, :217-218): chained step() over the first frames with `sigma` set.
+    The prior couples consecutive pairs through `_last_estimated_transform`, so this is a sequential run."""
+    dvo = get_dvo("robust-dvo", cam, Se3.identity(), levels=4, max_iterations=10, sigma=sigma)
+    c = np.repeat(frames[0][0][..., None], 3, axis=2)
+    dvo.step(color_image=c, depth_image=frames[0][1].copy())
+    out = {"sigma": np.float64(sigma)}
+    allrec, pair_idx, finals = [], [], []
+    for k in range(1, n_frames):
+        rec = Recorder(dvo)
+        try:
+            c = np.repeat(frames[k][0][..., None], 3, axis=2)
+            tf = dvo.step(color_image=c, depth_image=frames[k][1].copy())
+        finally:
+            rec.close()
+        allrec += rec.records
+        pair_idx += [k - 1] * len(rec.records)
+        finals.append(se3_to_arrays(tf))
+    packed = pack_records(allrec)
+    for key in ("level", "n", "T", "H32", "b32", "inc32", "H64", "b64"):      # H64/b64: data term only (no prior)
+        out[key] = packed[key]
+    out["pair"] = np.array(pair_idx)
+    for key in ("T", "xi", "quat", "tvec"):
+        out["final_" + key] = np.stack([f[key] for f in finals])
+    np.savez_compressed(OUT / "sigma_l4.npz", **out)
+    print("S sigma=%g: iterations per pair %s, xi=%s" % (sigma, np.bincount(out["pair"]).tolist(), out["final_xi"]), flush=True)
+
+
 def main():
     t_start = time.time()
     OUT.mkdir(parents=True, exist_ok=True)
     install_patches()
+    if "--only-sigma" in sys.argv:
+        install_fast_loops()
+        f = np.load(OUT / "frames.npz")
+        cam = RGBDCameraModel(np.array(f["intrinsics"], dtype=np.float32), float(f["depth_scale"]))
+        sigma_case(cam, [(f["gray"][i], f["depth"][i]) for i in range(10)])
+        return
 
     data_dir = REF / "tests" / "test_data"
     with (data_dir / "ground_truth.json").open() as fp:
@@ -419,6 +453,8 @@ def main():
         lie["comp_T"].append(np.array((s * prev).exp(), dtype=np.float32))
         prev = s
     np.savez_compressed(OUT / "lie.npz", **{k: np.stack(v) if isinstance(v, list) else v for k, v in lie.items()})
+
+    sigma_case(cam, frames)
 
     meta["elapsed_s"] = time.time() - t_start
     with (OUT / "meta.json").open("w") as fp:

@@ -331,6 +331,20 @@ def test_device_solve_student_t_and_v2(hip, golden_dir):
     np.testing.assert_allclose(res["xi"][0], ga["final_xi"], rtol=0, atol=1e-6)
 
 
+@pytest.mark.parametrize("solver", ["host", "device"])
+def test_motion_prior_sigma_vs_reference_run(frames, golden_dir, solver):
+    """sigma prior (base_robust_dvo.py:190-194,:217-218) through step(): iteration counts and poses of the
+    reference run (which itself carries ~1e-6 of float32 rounding from adding 1e13 to a float32 H)."""
+    g = np.load(golden_dir / "sigma_l4.npz")
+    dvo, _ = _make_dvo(frames, levels=4, max_iterations=10, sigma=float(g["sigma"]), solver=solver)
+    for k in range(4):
+        c = np.repeat(frames["gray"][k][..., None], 3, axis=2)
+        tf = dvo.step(c, frames["depth"][k].copy())
+        if k:
+            assert dvo.last_iterations == int((g["pair"] == k - 1).sum())
+            np.testing.assert_allclose(tf.log().reshape(6), g["final_xi"][k - 1], rtol=0, atol=5e-6)
+
+
 def test_sequence_pose_chain_vs_reference_run(frames, golden_dir):
     """step() over the ten fixture frames: current_pose chain (base_dense_visual_odometry.py:79)."""
     import dvo_amd

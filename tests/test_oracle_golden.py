@@ -244,3 +244,21 @@ def test_sequence_pose_chain(frames, golden_dir):
         tf = O.Pose(pairs["final_quat"][k], pairs["final_tvec"][k])
         pose = pose.mul(tf.inverse())
         np.testing.assert_allclose(pose.matrix(), g["pose_T"][k + 1], atol=2e-6)
+
+
+def test_gauss_newton_motion_prior_sequence(frames, golden_dir):
+    """sigma prior (base_robust_dvo.py:190-194,:217-218): chained pairs, coupled through the last transform.
+    The reference adds 1/sigma = 1e13 to a float32 H of ~1e14, so its own rounding is ~1e-6 on xi."""
+    g = np.load(golden_dir / "sigma_l4.npz")
+    last = O.Pose.identity()
+    for k in range(3):
+        rec = []
+        est = O.gauss_newton(frames["gray"][k], frames["depth"][k], frames["gray"][k + 1], frames["K"],
+                             frames["depth_scale"], levels=4, max_iterations=10, sigma=float(g["sigma"]),
+                             last_transform=last, record=rec)
+        assert len(rec) == int((g["pair"] == k).sum())            # [36, 22, 9]: the prior trips the stop rule early
+        np.testing.assert_allclose(est.log(), g["final_xi"][k], rtol=0, atol=5e-6)
+        last = est
+    # the prior matters at this sigma: the unconstrained solution is far away
+    free = np.load(golden_dir / "pairs_l4.npz")["final_xi"][0]
+    assert np.abs(free - g["final_xi"][0]).max() > 1e-3
