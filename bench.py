@@ -102,7 +102,8 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (no CPU fallback)")
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    use_dist = world > 1 or os.environ.get("DVO_BENCH_FORCE_DIST") == "1"     # (the env var rehearses the RCCL path on 1 GPU)
+    if use_dist:
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
 
     from dvo_amd import synthetic
@@ -127,7 +128,7 @@ def main():
 
     def step():
         res = al.align_device(gray.data_ptr(), depth.data_ptr(), n_frames)
-        if world > 1:
+        if use_dist:
             allgather_poses(pose_records(res["T"], res["iters"], res["err"]), counts, device="cuda")
         return res
 
@@ -139,7 +140,7 @@ def main():
     def fence():
         al.synchronize()
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
 
     fence()
@@ -148,7 +149,7 @@ def main():
         res = step()
     fence()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
@@ -212,7 +213,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline(st_np, L, args.iterations, args.cpu_pairs)
         print(json.dumps(out))
     al.close()
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

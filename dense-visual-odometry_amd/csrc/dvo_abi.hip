@@ -83,6 +83,8 @@ struct dvo_ctx {
     bool profiling = false;
     hipEvent_t ev_a = nullptr, ev_b = nullptr;
     hipEvent_t tm_a = nullptr, tm_b = nullptr;
+    hipEvent_t ev_staging = nullptr;
+    bool staging_in_flight = false;
     struct PendingEv { hipEvent_t a, b; int level; };
     std::vector<PendingEv> pending;
     std::vector<hipEvent_t> ev_pool;
@@ -388,6 +390,7 @@ int dvo_create(int device, int max_w, int max_h, int max_levels, int n_slots, in
     CREATE_TRY(hipHostMalloc((void**)&ctx->hs.err, np * sizeof(double)));
     CREATE_TRY(hipEventCreate(&ctx->tm_a));
     CREATE_TRY(hipEventCreate(&ctx->tm_b));
+    CREATE_TRY(hipEventCreateWithFlags(&ctx->ev_staging, hipEventDisableTiming));
     CREATE_TRY(hipStreamSynchronize(ctx->stream));
     {
         const char* e = getenv("DVO_GRAPH");
@@ -408,6 +411,7 @@ void dvo_destroy(dvo_ctx* ctx)
     for (auto& g : ctx->graphs) (void)hipGraphExecDestroy(g.exec);
     if (ctx->tm_a) (void)hipEventDestroy(ctx->tm_a);
     if (ctx->tm_b) (void)hipEventDestroy(ctx->tm_b);
+    if (ctx->ev_staging) (void)hipEventDestroy(ctx->ev_staging);
     void* dev[] = {ctx->d_slots, ctx->d_prev, ctx->d_cur, ctx->d_T, ctx->d_Tinit, ctx->d_wparam, ctx->d_active, ctx->d_partials,
                    ctx->d_out, ctx->d_state, ctx->d_xi, ctx->d_iters, ctx->d_err, ctx->d_stage_img, ctx->d_dense, ctx->d_trace, ctx->d_frame_slots, ctx->d_prior};
     for (void* p : dev) if (p) (void)hipFree(p);
@@ -600,6 +604,11 @@ int dvo_download_level(dvo_ctx* ctx, int slot, int level, uint8_t* gray, uint16_
 static int stage_pairs(dvo_ctx* ctx, int n_pairs, const int* prev_slot, const int* cur_slot, const float* T,
                        const double* wparam)
 {
+    // the pinned staging buffers may still be the source of an in-flight async copy of an earlier enqueue
+    if (ctx->staging_in_flight) {
+        HIP_TRY(ctx, hipEventSynchronize(ctx->ev_staging));
+        ctx->staging_in_flight = false;
+    }
     memcpy(ctx->hs.prev, prev_slot, n_pairs * sizeof(int));
     memcpy(ctx->hs.cur, cur_slot, n_pairs * sizeof(int));
     HIP_TRY(ctx, hipMemcpyAsync(ctx->d_prev, ctx->hs.prev, n_pairs * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
@@ -612,6 +621,8 @@ static int stage_pairs(dvo_ctx* ctx, int n_pairs, const int* prev_slot, const in
         memcpy(ctx->hs.wparam, wparam, n_pairs * sizeof(double));
         HIP_TRY(ctx, hipMemcpyAsync(ctx->d_wparam, ctx->hs.wparam, n_pairs * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
     }
+    HIP_TRY(ctx, hipEventRecord(ctx->ev_staging, ctx->stream));
+    ctx->staging_in_flight = true;
     return DVO_OK;
 }
 
@@ -781,6 +792,7 @@ int dvo_solve_batch_enqueue(dvo_ctx* ctx, int n_pairs, const int* prev_slot, con
     if (T_init) {
         memcpy(ctx->hs.T, T_init, (size_t)n_pairs * 12 * sizeof(float));
         HIP_TRY(ctx, hipMemcpyAsync(ctx->d_Tinit, ctx->hs.T, (size_t)n_pairs * 12 * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+        HIP_TRY(ctx, hipEventRecord(ctx->ev_staging, ctx->stream));
         d_init = ctx->d_Tinit;
     }
     // The launch sequence of the whole solve is fixed by (batch size, image size, levels, iterations, modes): it is
