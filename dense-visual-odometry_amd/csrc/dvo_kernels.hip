@@ -357,6 +357,39 @@ __device__ __forceinline__ double wave_sum(double v)
     return v;
 }
 
+// Workgroup (256 threads) reduction of the DVO_NACC per-lane float32 sums into out[0..31] (float64; global or LDS).
+// The sums are transposed through LDS instead of 30 x 6 cross-lane butterflies: every lane stores its sums
+// ([term][thread], padded so stores and loads are bank-conflict free), then 8 lanes per term each add 32 of the 256
+// values in float64 (fixed order => reproducible), and a 3-step shuffle joins the 8 segments.  Two rounds of 15
+// terms keep the LDS footprint at 15.5 KB per workgroup.
+__device__ __forceinline__ void block_reduce_terms(const float* acc, double* out)
+{
+    constexpr int ROW = 8 * 33;                          // 8 segments of 32 values + 1 pad each
+    constexpr int HALF = 15;
+    __shared__ float tbuf[HALF * ROW];
+    const int t = threadIdx.x;
+    const int wpos = (t >> 5) * 33 + (t & 31);
+    const int term = t >> 3, segi = t & 7;
+#pragma unroll
+    for (int round = 0; round < 2; ++round) {
+        if (round) __syncthreads();                      // previous round's loads are done
+#pragma unroll
+        for (int i = 0; i < HALF; ++i) tbuf[i * ROW + wpos] = acc[round * HALF + i];
+        __syncthreads();
+        double sgm = 0.0;
+        if (t < HALF * 8) {
+            const float* src = tbuf + term * ROW + segi * 33;
+#pragma unroll 8
+            for (int k = 0; k < 32; ++k) sgm += (double)src[k];
+        }
+        sgm += __shfl_xor(sgm, 1, 64);
+        sgm += __shfl_xor(sgm, 2, 64);
+        sgm += __shfl_xor(sgm, 4, 64);
+        if (t < HALF * 8 && segi == 0) out[round * HALF + term] = sgm;
+    }
+    if (t >= 30 && t < DVO_STRIDE) out[t] = 0.0;
+}
+
 #ifndef DVO_REDUCE_WAVES_PER_SIMD
 #define DVO_REDUCE_WAVES_PER_SIMD 4
 #endif
@@ -495,31 +528,8 @@ __global__ __launch_bounds__(DVO_BLOCK, DVO_REDUCE_WAVES_PER_SIMD) void k_reduce
             p.partials[((size_t)pair * p.blocks_per_pair + blk) * DVO_STRIDE + threadIdx.x] = tot;
         }
     } else {
-        constexpr int ROW = 8 * 33;                          // 8 segments of 32 values + 1 pad each
-        constexpr int HALF = 15;
-        __shared__ float tbuf[HALF * ROW];
-        const int t = threadIdx.x;
-        const int wpos = (t >> 5) * 33 + (t & 31);
-        const int term = t >> 3, segi = t & 7;
         double* out = p.partials + ((size_t)pair * p.blocks_per_pair + blk) * DVO_STRIDE;
-#pragma unroll
-        for (int round = 0; round < 2; ++round) {
-            if (round) __syncthreads();                      // previous round's loads are done
-#pragma unroll
-            for (int i = 0; i < HALF; ++i) tbuf[i * ROW + wpos] = acc[round * HALF + i];
-            __syncthreads();
-            double sgm = 0.0;
-            if (t < HALF * 8) {
-                const float* src = tbuf + term * ROW + segi * 33;
-#pragma unroll 8
-                for (int k = 0; k < 32; ++k) sgm += (double)src[k];
-            }
-            sgm += __shfl_xor(sgm, 1, 64);
-            sgm += __shfl_xor(sgm, 2, 64);
-            sgm += __shfl_xor(sgm, 4, 64);
-            if (t < HALF * 8 && segi == 0) out[round * HALF + term] = sgm;
-        }
-        if (t >= 30 && t < DVO_STRIDE) out[t] = 0.0;
+        block_reduce_terms(acc, out);
     }
 }
 
@@ -940,14 +950,10 @@ hipError_t dvo_launch_level_begin(DvoPairState* st, int* active, double* wparam,
     return hipGetLastError();
 }
 
-// One workgroup per pair: sum partials, then lane 0 runs the scalar control of one GN iteration.
-__global__ __launch_bounds__(DVO_BLOCK) void k_solve(const DvoSolveParams p)
+// Scalar control of one Gauss-Newton iteration of one pair (run by ONE thread): base_robust_dvo.py:166-232.
+// `rec` is the summed normal-equation record (modified in place when the motion prior is on).
+__device__ __forceinline__ void gn_control(const DvoSolveParams& p, int pair, double* rec)
 {
-    const int pair = blockIdx.x;
-    if (p.active[pair] == 0) return;
-    __shared__ double rec[DVO_STRIDE];
-    sum_partials_block(p.partials + (size_t)pair * p.blocks_per_pair * DVO_STRIDE, p.blocks_per_pair, rec);
-    if (threadIdx.x != 0) return;
     DvoPairState& st = p.state[pair];
 
     if (p.phase != 0) {
@@ -1017,6 +1023,17 @@ __global__ __launch_bounds__(DVO_BLOCK) void k_solve(const DvoSolveParams p)
         st.lambda = (sig > 0.0) ? p.weight_param * sig : -1.0;
         p.wparam[pair] = (st.lambda > 0.0) ? st.lambda : DVO_FLT_MAX;
     }
+}
+
+// One workgroup per pair: sum partials, then lane 0 runs the scalar control of one GN iteration.
+__global__ __launch_bounds__(DVO_BLOCK) void k_solve(const DvoSolveParams p)
+{
+    const int pair = blockIdx.x;
+    if (p.active[pair] == 0) return;
+    __shared__ double rec[DVO_STRIDE];
+    sum_partials_block(p.partials + (size_t)pair * p.blocks_per_pair * DVO_STRIDE, p.blocks_per_pair, rec);
+    if (threadIdx.x != 0) return;
+    gn_control(p, pair, rec);
 }
 
 hipError_t dvo_launch_solve(const DvoSolveParams& p, hipStream_t s)
