@@ -390,6 +390,9 @@ __device__ __forceinline__ void block_reduce_terms(const float* acc, double* out
     if (t >= 30 && t < DVO_STRIDE) out[t] = 0.0;
 }
 
+#ifndef DVO_COMPACT
+#define DVO_COMPACT 1
+#endif
 #ifndef DVO_REDUCE_WAVES_PER_SIMD
 #define DVO_REDUCE_WAVES_PER_SIMD 4
 #endif
@@ -446,6 +449,9 @@ __global__ __launch_bounds__(DVO_BLOCK, DVO_REDUCE_WAVES_PER_SIMD) void k_reduce
         }
     }
     int vy0 = 0, ux0 = 0;       // pixel of this lane at the start of the current group (advanced incrementally)
+#if DVO_COMPACT
+    __shared__ uint2 cbuf[DVO_BLOCK / 64][64 * DVO_PX_PER_THREAD];
+#endif
     for (int grp = 0; grp < p.groups_per_block; ++grp) {
         const int seg = ((blk * p.groups_per_block + grp) * (DVO_BLOCK / 64) + wave_) * (64 * DVO_PX_PER_THREAD);
         if (seg >= p.g.npix) break;                                       // wave-uniform
@@ -463,22 +469,68 @@ __global__ __launch_bounds__(DVO_BLOCK, DVO_REDUCE_WAVES_PER_SIMD) void k_reduce
             }
         }
         if (grp == 0) { vy0 = (seg + lane_) / p.g.w; ux0 = (seg + lane_) - vy0 * p.g.w; }
-        int vy = vy0, ux = ux0;
+        int px[DVO_PX_PER_THREAD], py[DVO_PX_PER_THREAD];
+        {
+            int vy = vy0, ux = ux0;
+#pragma unroll
+            for (int j = 0; j < DVO_PX_PER_THREAD; ++j) {
+                px[j] = ux; py[j] = vy;
+                ux += 64;
+                while (ux >= p.g.w) { ux -= p.g.w; ++vy; }
+            }
+            ux0 = ux + (DVO_BLOCK / 64 - 1) * (64 * DVO_PX_PER_THREAD);      // same lane, next group of this wave
+            vy0 = vy;
+            while (ux0 >= p.g.w) { ux0 -= p.g.w; ++vy0; }
+        }
+#if DVO_COMPACT
+        // Wave-level compaction: ~30 % of the pixels have no depth, and a wave runs a pixel round at full cost as
+        // long as one lane is live.  The depth-valid pixels of the wave's 256 are packed (ballot + mbcnt prefix,
+        // one 8-byte LDS slot each) and dealt back to the lanes densely, so the last round(s) of the group are
+        // empty for every lane and are skipped by the existing per-round branches.
+        {
+            // (only when it buys at least one empty round: a segment with more than 192 live pixels needs all 4)
+            unsigned long long m[DVO_PX_PER_THREAD];
+            unsigned nvalid = 0;
+#pragma unroll
+            for (int j = 0; j < DVO_PX_PER_THREAD; ++j) {
+                m[j] = __builtin_amdgcn_ballot_w64(dd[j] != 0u);
+                nvalid += (unsigned)__builtin_popcountll(m[j]);
+            }
+            if (nvalid <= 64u * (DVO_PX_PER_THREAD - 1) && nvalid > 0u) {          // wave-uniform
+                uint2* cb = cbuf[wave_];
+                unsigned base = 0;
+#pragma unroll
+                for (int j = 0; j < DVO_PX_PER_THREAD; ++j) {
+                    const unsigned pos = base + __builtin_amdgcn_mbcnt_hi((unsigned)(m[j] >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m[j], 0u));
+                    if (dd[j] != 0u) cb[pos] = make_uint2(dd[j] | (ii[j] << 16), (unsigned)px[j] | ((unsigned)py[j] << 16));
+                    base += (unsigned)__builtin_popcountll(m[j]);
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+                for (int j = 0; j < DVO_PX_PER_THREAD; ++j) {
+                    const unsigned e = (unsigned)(j * 64 + lane_);
+                    const uint2 c = cb[e < nvalid ? e : 0u];
+                    const bool live = e < nvalid;
+                    dd[j] = live ? (c.x & 0xffffu) : 0u;
+                    ii[j] = c.x >> 16;
+                    px[j] = (int)(c.y & 0xffffu);
+                    py[j] = (int)(c.y >> 16);
+                }
+            }
+        }
+#endif
         // phase A for all pixels of the lane, then all tap loads back to back (memory-level parallelism: the
         // dependent gathers of 4 pixels are in flight together), then phase B
         PixelGeo geo[DVO_PX_PER_THREAD];
         PixelTaps taps[DVO_PX_PER_THREAD];
 #pragma unroll
         for (int j = 0; j < DVO_PX_PER_THREAD; ++j) {
-            dvo_geo(p.g, p.cam, p.depth_scale, T, ux, vy, dd[j], geo[j]);
+            dvo_geo(p.g, p.cam, p.depth_scale, T, px[j], py[j], dd[j], geo[j]);
             dvo_load_taps(p.g, packed_cur, geo[j], taps[j]);
-            if (VARIANT == 1) taps[j].own = geo[j].ok ? packed_prev[(unsigned)(vy * p.g.pitch + ux)] : 0u;
-            ux += 64;
-            while (ux >= p.g.w) { ux -= p.g.w; ++vy; }
+            if (VARIANT == 1) taps[j].own = geo[j].ok ? packed_prev[(unsigned)(py[j] * p.g.pitch + px[j])] : 0u;
         }
-        ux0 = ux + (DVO_BLOCK / 64 - 1) * (64 * DVO_PX_PER_THREAD);          // same lane, next group of this wave
-        vy0 = vy;
-        while (ux0 >= p.g.w) { ux0 -= p.g.w; ++vy0; }
 #pragma unroll
         for (int j = 0; j < DVO_PX_PER_THREAD; ++j) {
             if (geo[j].ok) {                                  // depth != 0 (camera_model.py:195) and in bounds
