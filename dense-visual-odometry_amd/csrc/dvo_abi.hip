@@ -859,6 +859,23 @@ int dvo_solve_batch(dvo_ctx* ctx, int n_pairs, const int* prev_slot, const int* 
     return dvo_solve_batch_fetch(ctx, n_pairs, T_out, xi_out, iters_out, err_out);
 }
 
+int dvo_debug_divide(dvo_ctx* ctx, const float* a, const float* b, float* out, float* ref, int n)
+{
+    if (!ctx || !a || !b || !out || !ref || n <= 0) return DVO_ERR_INVALID_ARG;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    float* d = nullptr;
+    HIP_TRY(ctx, hipMalloc((void**)&d, (size_t)n * 4 * sizeof(float)));
+    hipError_t e = hipMemcpyAsync(d, a, (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(d + n, b, (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = dvo_launch_debug_divide(d, d + n, d + 2 * (size_t)n, d + 3 * (size_t)n, n, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(out, d + 2 * (size_t)n, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(ref, d + 3 * (size_t)n, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    (void)hipFree(d);
+    HIP_TRY(ctx, e);
+    return DVO_OK;
+}
+
 int dvo_set_prior(dvo_ctx* ctx, double sigma, const double* last_qt, int n_pairs)
 {
     if (!ctx) return DVO_ERR_INVALID_ARG;

@@ -119,5 +119,6 @@ hipError_t dvo_launch_init_state(DvoPairState* st, float* T, const float* T_init
 hipError_t dvo_launch_level_begin(DvoPairState* st, int* active, double* wparam, int n_pairs, int weight_mode,
                                   double lambda0, hipStream_t s);
 hipError_t dvo_launch_solve(const DvoSolveParams& p, hipStream_t s);
+hipError_t dvo_launch_debug_divide(const float* a, const float* b, float* out, float* ref, int n, hipStream_t s);
 hipError_t dvo_launch_finish(const DvoPairState* st, int n_pairs, double* xi_out, int* iters_out, double* err_out,
                              hipStream_t s);

@@ -269,6 +269,15 @@ __device__ __forceinline__ float dvo_depth_to_z(unsigned d, double depth_scale, 
     return (float)((double)d * depth_scale);
 }
 
+__device__ __forceinline__ float dvo_div_with_rcp(float a, float b, float rb)
+{
+    const float q0 = a * rb;
+    const float e0 = fmaf(-b, q0, a);
+    const float q1 = fmaf(e0, rb, q0);
+    const float e1 = fmaf(-b, q1, a);
+    return fmaf(e1, rb, q1);
+}
+
 __device__ __forceinline__ void dvo_geo(const DvoLevelGeom& g, const DvoLevelCam& cam, double depth_scale,
                                         const float* __restrict__ T, int ux, int vy, unsigned d, PixelGeo& o)
 {
@@ -290,12 +299,21 @@ __device__ __forceinline__ void dvo_geo(const DvoLevelGeom& g, const DvoLevelCam
     const float zp = ((T[8] * x + T[9] * y) + T[10] * z) + T[11];
     const float un = cam.skew0 ? ((cam.fx * xp) + (cam.cx * zp)) : (((cam.fx * xp) + (cam.s * yp)) + (cam.cx * zp));
     const float vn = (cam.fy * yp) + (cam.cy * zp);
-    const float uw = un / zp;      // IEEE division (hipcc default: correctly rounded)
-    const float vw = vn / zp;
+    // Correctly rounded quotients.  This is exactly the arithmetic core of the compiler's IEEE float32 division
+    // (v_rcp_f32, two Newton steps on the reciprocal/quotient, final fma) without the v_div_scale / v_div_fixup
+    // wrappers, which only rescale when the quotient or an intermediate leaves the normal range (|a/b| beyond
+    // 2^+-96, denormals) and patch up inf / NaN / 0: for pixel coordinates (|a/b| < 1e5, |b| ~ 1) they are
+    // identities, and 1/zp is shared by both quotients.  A non-finite or zero zp gives NaN here instead of +-inf:
+    // invalid either way.  Checked bit for bit against `/` in tests (dvo_debug_divide).
+    const float rz0 = __builtin_amdgcn_rcpf(zp);
+    const float rz = fmaf(fmaf(-zp, rz0, 1.0f), rz0, rz0);
+    const float uw = dvo_div_with_rcp(un, zp, rz);
+    const float vw = dvo_div_with_rcp(vn, zp, rz);
     // closed-boundary rule: valid <=> 0 <= x <= W-1 and 0 <= y <= H-1 ; NaN compares false
     const bool ok = (uw >= 0.0f) && (uw <= (float)(g.w - 1)) && (vw >= 0.0f) && (vw <= (float)(g.h - 1));
     o.x = x; o.y = y; o.z = z; o.uw = uw; o.vw = vw; o.ok = ok;
-    o.off = ok ? (unsigned)((int)floorf(vw) * g.pitch + (int)floorf(uw)) : 0u;
+    // tap offset y0 * pitch + x0, formed in float32 (exact: < 2^24) to save a conversion and an integer multiply
+    o.off = ok ? (unsigned)fmaf(floorf(vw), (float)g.pitch, floorf(uw)) : 0u;
 }
 
 __device__ __forceinline__ void dvo_load_taps(const DvoLevelGeom& g, const uint32_t* __restrict__ cur,
@@ -345,6 +363,23 @@ __device__ __forceinline__ void dvo_finish(const DvoLevelCam& cam, const PixelGe
     o.J[3] = -fmaf(fxg, ab, fyg * fmaf(b, b, 1.0f));
     o.J[4] = fmaf(fxg, fmaf(a, a, 1.0f), fyg * ab);
     o.J[5] = fmaf(fyg, a, -(fxg * b));
+}
+
+// Test hook: out[i] = the kernels' quotient a[i]/b[i]; ref[i] = the compiler's IEEE division.
+__global__ void k_debug_divide(const float* a, const float* b, float* out, float* ref, int n)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float rz0 = __builtin_amdgcn_rcpf(b[i]);
+    const float rz = fmaf(fmaf(-b[i], rz0, 1.0f), rz0, rz0);
+    out[i] = dvo_div_with_rcp(a[i], b[i], rz);
+    ref[i] = a[i] / b[i];
+}
+
+hipError_t dvo_launch_debug_divide(const float* a, const float* b, float* out, float* ref, int n, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_debug_divide, dim3((n + 255) / 256), dim3(256), 0, s, a, b, out, ref, n);
+    return hipGetLastError();
 }
 
 // ================================================================================================

@@ -60,6 +60,7 @@ SIGNATURES = {
     "dvo_solve_batch_enqueue": (C.c_int, [_ctx, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_double,
                                           C.c_int, C.c_int, C.c_int, C.c_double, C.c_void_p]),
     "dvo_solve_batch_fetch": (C.c_int, [_ctx, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "dvo_debug_divide": (C.c_int, [_ctx, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]),
     "dvo_set_prior": (C.c_int, [_ctx, C.c_double, C.c_void_p, C.c_int]),
     "dvo_trace_enable": (C.c_int, [_ctx, C.c_int]),
     "dvo_trace_read": (C.c_int, [_ctx, C.c_int, C.c_void_p]),
@@ -306,6 +307,15 @@ class HipContext:
             return
         q = None if last_qt is None else _as(last_qt, np.float64).reshape(-1, 7)
         self._check(self._lib.dvo_set_prior(self._h, float(sigma), _ptr(q), 0 if q is None else q.shape[0]))
+
+    def debug_divide(self, a: np.ndarray, b: np.ndarray):
+        """(kernel quotient, IEEE quotient) computed on the device for float32 arrays a, b."""
+        a = _as(a, np.float32).reshape(-1)
+        b = _as(b, np.float32).reshape(-1)
+        out = np.empty_like(a)
+        ref = np.empty_like(a)
+        self._check(self._lib.dvo_debug_divide(self._h, _ptr(a), _ptr(b), _ptr(out), _ptr(ref), a.shape[0]))
+        return out, ref
 
     def trace_enable(self, cap: int):
         self._check(self._lib.dvo_trace_enable(self._h, cap))

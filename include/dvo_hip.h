@@ -161,6 +161,10 @@ int dvo_set_prior(dvo_ctx* ctx, double sigma, const double* last_qt, int n_pairs
 int dvo_trace_enable(dvo_ctx* ctx, int max_iterations_traced);
 int dvo_trace_read(dvo_ctx* ctx, int n_pairs, double* out /* n_pairs x cap x DVO_TRACE_STRIDE */);
 
+/* Test hook: out[i] = the quotient a[i]/b[i] as the kernels' projection computes it (shared reciprocal + two
+ * correction steps), ref[i] = the compiler's IEEE division on the device.  Host arrays of n floats. */
+int dvo_debug_divide(dvo_ctx* ctx, const float* a, const float* b, float* out, float* ref, int n);
+
 /* ---- measurement ------------------------------------------------------------------------------- */
 
 /* When enabled, every launch of the reduction kernel is bracketed by HIP events on the ctx stream. */

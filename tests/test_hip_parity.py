@@ -505,3 +505,22 @@ def test_full_size_1280x960_properties():
         # (e) a solve from a perturbed start on identical frames walks back towards the identity
         res = ctx.solve_batch([0], [1], levels=levels, max_iterations=10, T_init=T)
         assert np.linalg.norm(res["xi"][0]) < 0.2 * np.linalg.norm([0.004, -0.003, 0.002, 0.002, -0.001, 0.003])
+
+
+def test_projection_division_is_bit_identical_to_ieee(hip):
+    """The projection's quotient (shared reciprocal + two correction steps, no v_div_scale / v_div_fixup) against the
+    compiler's IEEE division on the device and against NumPy, over the operand ranges the projection sees."""
+    ctx, _ = hip
+    rng = np.random.default_rng(2024)
+    n = 1 << 22
+    for lo, hi, scale in ((0.05, 20.0, 3000.0), (0.3, 6.0, 800.0), (1e-3, 1e3, 1e6)):
+        b = rng.uniform(lo, hi, n).astype(np.float32)
+        a = (rng.uniform(-1.0, 1.0, n) * scale * b).astype(np.float32)
+        out, ref = ctx.debug_divide(a, b)
+        assert np.array_equal(out.view(np.uint32), ref.view(np.uint32))
+        assert np.array_equal(out, a / b)
+    # negative / tiny denominators keep the same answer too; zero gives a non-finite value (pixel invalid either way)
+    b = np.array([-2.5, -0.01, 1e-20, 0.0], dtype=np.float32)
+    a = np.array([100.0, 3.0, 1e-18, 5.0], dtype=np.float32)
+    out, ref = ctx.debug_divide(a, b)
+    assert np.array_equal(out[:3], ref[:3]) and not np.isfinite(out[3]) and not np.isfinite(ref[3])
