@@ -324,8 +324,51 @@ __device__ __forceinline__ void dvo_load_taps(const DvoLevelGeom& g, const uint3
     t.t1 = *reinterpret_cast<const u32x2_a4*>(row0 + g.pitch);
 }
 
+// Variant V3 (the reference's numba.cuda kernel, cuda/residuals_kernel.py:46-109): phase A with the arithmetic types
+// numba infers for that source — `tx - cx` is int32 - float32 = float64, so back-projection, rigid transform, the six
+// Jacobian terms and the projection are float64 expressions (rounded to float32 where the kernel stores / passes
+// float32); z = depth * depth_scale and the clamped central-difference gradient of I1 are float32; strict bilinear
+// bounds (x1 < W, y1 < H, :30-31).  The Jacobian needs no tap of I2, so it is finished here.
+__device__ __forceinline__ void dvo_geo_v3(const DvoLevelGeom& g, const DvoLevelCam& cam, double depth_scale,
+                                           const float* __restrict__ T, const uint8_t* __restrict__ gray_prev,
+                                           int ux, int vy, unsigned d, PixelGeo& o, float* __restrict__ J)
+{
+    o.ok = false;
+    o.off = 0u;
+    o.x = o.y = o.z = 0.0f;
+    o.uw = o.vw = __builtin_nanf("");
+#pragma unroll
+    for (int k = 0; k < 6; ++k) J[k] = 0.0f;
+    if (d == 0u) return;                                                          // :60-65
+    const double z = (double)((float)d * (float)depth_scale);                     // :67 uint16 * float32 -> float32
+    const double fx = cam.fx, fy = cam.fy, cx = cam.cx, cy = cam.cy;
+    const double x = ((double)ux - cx) * z / fx;                                  // :69-70
+    const double y = ((double)vy - cy) * z / fy;
+    const double x1 = (((double)T[0] * x + (double)T[1] * y) + (double)T[2] * z) + (double)T[3];     // :73-75
+    const double y1 = (((double)T[4] * x + (double)T[5] * y) + (double)T[6] * z) + (double)T[7];
+    const double z1 = (((double)T[8] * x + (double)T[9] * y) + (double)T[10] * z) + (double)T[11];
+    const uint8_t* row = gray_prev + (size_t)vy * g.w;
+    const double gx = (double)(0.5f * ((float)row[min(ux + 1, g.w - 1)] - (float)row[max(ux - 1, 0)]));            // :8-19
+    const double gy = (double)(0.5f * ((float)gray_prev[(size_t)min(vy + 1, g.h - 1) * g.w + ux] -
+                                       (float)gray_prev[(size_t)max(vy - 1, 0) * g.w + ux]));
+    const double z2 = z1 * z1;
+    J[0] = (float)(fx * gx / z1);                                                 // :87-92
+    J[1] = (float)(fy * gy / z1);
+    J[2] = (float)((-fx) * gx * x1 / z2 - fy * gy * y1 / z2);
+    J[3] = (float)((-fx) * gx * x1 * y1 / z2 - fy * gy * ((y1 * y1) / z2 + 1.0));
+    J[4] = (float)(fx * gx * ((x1 * x1) / z2 + 1.0) + fy * gy * x1 * y1 / z2);
+    J[5] = (float)((-fx) * gx * y1 / z1 + fy * gy * x1 / z1);
+    const float wx = (float)(fx * x1 / z1 + cx);                                  // :95-96, float32 argument of :99
+    const float wy = (float)(fy * y1 / z1 + cy);
+    const float x0 = floorf(wx), y0 = floorf(wy);
+    const bool ok = (x0 >= 0.0f) && (y0 >= 0.0f) && (x0 + 1.0f < (float)g.w) && (y0 + 1.0f < (float)g.h);
+    o.uw = wx; o.vw = wy; o.ok = ok;
+    o.off = ok ? (unsigned)fmaf(y0, (float)g.pitch, x0) : 0u;
+}
+
 // Phase B: bilinear photometric lookup, residual, 1x6 Jacobian row.
-// VARIANT 0 (V1): gradient of I2 sampled at the warped point; 1 (V2): Sobel gradient of I1 at the pixel.
+// VARIANT 0 (V1): gradient of I2 sampled at the warped point; 1 (V2): Sobel gradient of I1 at the pixel;
+// 2 (V3): Jacobian row already finished by dvo_geo_v3, only the residual is computed here.
 template <int VARIANT, bool NEED_J>
 __device__ __forceinline__ void dvo_finish(const DvoLevelCam& cam, const PixelGeo& q, const PixelTaps& t,
                                            unsigned i1, PixelOut& o)
@@ -342,7 +385,7 @@ __device__ __forceinline__ void dvo_finish(const DvoLevelCam& cam, const PixelGe
     unpack_tap(t.t1.b, I11, gx11, gy11);
     const float i2 = fmaf(w11, I11, fmaf(w10, I10, fmaf(w01, I01, w00 * I00)));
     o.r = i2 - (float)i1;                                                       // :191-194
-    if (!NEED_J) return;
+    if (!NEED_J || VARIANT == 2) return;        // V3: the Jacobian row was finished in phase A (dvo_geo_v3)
     float gxw, gyw;
     if (VARIANT == 0) {
         gxw = fmaf(w11, gx11, fmaf(w10, gx10, fmaf(w01, gx01, w00 * gx00)));    // :123-128
@@ -434,7 +477,7 @@ __device__ __forceinline__ void block_reduce_terms(const float* acc, double* out
 // TAG only names the instantiation so that rocprofv3 --stats lists these dispatches on their own line; codegen is
 // identical.  0: coarser levels, 1: level 0, 2: level 0 while the ctx is in profiling mode (bench.py's roofline leg).
 template <int VARIANT, int WMODE, bool SCALE_PASS, int TAG>
-__global__ __launch_bounds__(DVO_BLOCK, DVO_REDUCE_WAVES_PER_SIMD) void k_reduce(const DvoReduceParams p)
+__global__ __launch_bounds__(DVO_BLOCK, (VARIANT == 2) ? 2 : DVO_REDUCE_WAVES_PER_SIMD) void k_reduce(const DvoReduceParams p)
 {
     constexpr int NACC = SCALE_PASS ? 1 : DVO_NACC;
     // XCD-aware block order (speed only): workgroups are dealt round-robin to the 8 XCDs, so give XCD k the
@@ -560,9 +603,11 @@ __global__ __launch_bounds__(DVO_BLOCK, DVO_REDUCE_WAVES_PER_SIMD) void k_reduce
         // dependent gathers of 4 pixels are in flight together), then phase B
         PixelGeo geo[DVO_PX_PER_THREAD];
         PixelTaps taps[DVO_PX_PER_THREAD];
+        float jv3[(VARIANT == 2) ? DVO_PX_PER_THREAD : 1][6];
 #pragma unroll
         for (int j = 0; j < DVO_PX_PER_THREAD; ++j) {
-            dvo_geo(p.g, p.cam, p.depth_scale, T, px[j], py[j], dd[j], geo[j]);
+            if constexpr (VARIANT == 2) dvo_geo_v3(p.g, p.cam, p.depth_scale, T, gray_prev, px[j], py[j], dd[j], geo[j], jv3[j]);
+            else dvo_geo(p.g, p.cam, p.depth_scale, T, px[j], py[j], dd[j], geo[j]);
             dvo_load_taps(p.g, packed_cur, geo[j], taps[j]);
             if (VARIANT == 1) taps[j].own = geo[j].ok ? packed_prev[(unsigned)(py[j] * p.g.pitch + px[j])] : 0u;
         }
@@ -571,6 +616,10 @@ __global__ __launch_bounds__(DVO_BLOCK, DVO_REDUCE_WAVES_PER_SIMD) void k_reduce
             if (geo[j].ok) {                                  // depth != 0 (camera_model.py:195) and in bounds
                 PixelOut o;
                 dvo_finish<VARIANT, !SCALE_PASS>(p.cam, geo[j], taps[j], ii[j], o);
+                if constexpr (VARIANT == 2) {
+#pragma unroll
+                    for (int k = 0; k < 6; ++k) o.J[k] = jv3[j][k];
+                }
                 const float r = o.r;
                 const float r2 = r * r;
                 if constexpr (SCALE_PASS) {
@@ -638,6 +687,7 @@ static hipError_t launch_reduce_v(const DvoReduceParams& p, int weight_mode, int
 
 hipError_t dvo_launch_reduce(const DvoReduceParams& p, int variant, int weight_mode, int scale_pass, hipStream_t s)
 {
+    if (variant == 2) return launch_reduce_v<2, 0>(p, weight_mode, scale_pass, s);      // V3: no per-level kernel tags
     if (p.finest == 2) {
         if (variant == 0) return launch_reduce_v<0, 2>(p, weight_mode, scale_pass, s);
         return launch_reduce_v<1, 2>(p, weight_mode, scale_pass, s);
@@ -713,12 +763,18 @@ __global__ __launch_bounds__(DVO_BLOCK) void k_dense(const DvoDenseParams p)
         float T[12];
 #pragma unroll
         for (int i = 0; i < 12; ++i) T[i] = p.T[i];
-        dvo_geo(p.g, p.cam, p.depth_scale, T, ux, vy, d, q);
+        float jpre[6];
+        if constexpr (VARIANT == 2) dvo_geo_v3(p.g, p.cam, p.depth_scale, T, gray_prev, ux, vy, d, q, jpre);
+        else dvo_geo(p.g, p.cam, p.depth_scale, T, ux, vy, d, q);
         if (q.ok) {
             PixelTaps t;
             dvo_load_taps(p.g, packed_cur, q, t);
             t.own = (VARIANT == 1) ? packed_prev[(size_t)vy * p.g.pitch + ux] : 0u;
             dvo_finish<VARIANT, true>(p.cam, q, t, gray_prev[idx], o);
+            if constexpr (VARIANT == 2) {
+#pragma unroll
+                for (int k = 0; k < 6; ++k) o.J[k] = jpre[k];
+            }
         }
     }
     if (p.r) p.r[idx] = o.r;
@@ -734,7 +790,8 @@ hipError_t dvo_launch_dense(const DvoDenseParams& p, int variant, hipStream_t s)
 {
     dim3 grid((p.g.npix + DVO_BLOCK - 1) / DVO_BLOCK), block(DVO_BLOCK);
     if (variant == 0) hipLaunchKernelGGL(k_dense<0>, grid, block, 0, s, p);
-    else hipLaunchKernelGGL(k_dense<1>, grid, block, 0, s, p);
+    else if (variant == 1) hipLaunchKernelGGL(k_dense<1>, grid, block, 0, s, p);
+    else hipLaunchKernelGGL(k_dense<2>, grid, block, 0, s, p);
     return hipGetLastError();
 }
 

@@ -25,7 +25,7 @@ class BatchAligner:
     def __init__(self, K: np.ndarray, depth_scale: float, width: int = 640, height: int = 480, levels: int = 4,
                  max_pairs: int = 64, device: int = 0, max_iterations: int = 10, tolerance: float = 1e-6,
                  max_increased_steps_allowed: int = 0, weighting: str = "none", huber_k: float = 1.345,
-                 approximate_image2_gradient: bool = False):
+                 approximate_image2_gradient: bool = False, reference_variant: str = "cpu"):
         if weighting not in _WEIGHTS:
             raise ValueError("weighting must be one of {}".format(sorted(_WEIGHTS)))
         self.width, self.height, self.levels, self.max_pairs = width, height, levels, max_pairs
@@ -33,6 +33,8 @@ class BatchAligner:
         self.max_increased = max_increased_steps_allowed
         self.weight_mode, self.huber_k = _WEIGHTS[weighting], huber_k
         self.variant = _cabi.VARIANT_V2 if approximate_image2_gradient else _cabi.VARIANT_V1
+        if reference_variant == "cuda":
+            self.variant = _cabi.VARIANT_V3
         self.ctx = _cabi.HipContext(device=device, max_w=width, max_h=height, max_levels=levels,
                                     n_slots=max_pairs + 1, max_pairs=max_pairs)
         K = np.asarray(K, dtype=np.float32)

@@ -38,7 +38,7 @@ class ImagePyramidError(Exception):
     pass
 
 
-_VARIANTS = {"v1": _cabi.VARIANT_V1, "v2": _cabi.VARIANT_V2}
+_VARIANTS = {"v1": _cabi.VARIANT_V1, "v2": _cabi.VARIANT_V2, "v3": _cabi.VARIANT_V3}
 _WEIGHTS = {"none": _cabi.WEIGHT_NONE, "student_t_reference": _cabi.WEIGHT_STUDENT_T, "huber": _cabi.WEIGHT_HUBER}
 
 
@@ -70,7 +70,7 @@ class RobustDVOHIP:
                  max_iterations: int = 100, approximate_image2_gradient: bool = False,
                  height: int = 480, width: int = 640, device: int = 0, solver: str = "host",
                  weighting: Optional[str] = None, huber_k: float = 1.345, max_distance: float = 5.0,
-                 mutate_depth: bool = True):
+                 mutate_depth: bool = True, reference_variant: str = "cpu"):
         if levels < 1:
             raise ValueError("Expected 'levels' to be >= 1, got '{}' instead".format(levels))
         if solver not in ("host", "device"):
@@ -87,7 +87,15 @@ class RobustDVOHIP:
         self._tolerance = tolerance
         self._max_iter = max_iterations
         self._approximate_image2_gradients = approximate_image2_gradient
-        self._variant = _cabi.VARIANT_V2 if approximate_image2_gradient else _cabi.VARIANT_V1
+        # which of the reference's behaviours to reproduce: "cpu" = RobustDVOCPU (V1, or V2 with
+        # approximate_image2_gradient), "cuda" = its numba.cuda kernel (V3: central-difference gradient of I1,
+        # J_w at the warped point, strict bilinear bounds, mask = depth-valid AND in bounds)
+        if reference_variant not in ("cpu", "cuda"):
+            raise ValueError("reference_variant must be 'cpu' or 'cuda', got '{}'".format(reference_variant))
+        if reference_variant == "cuda":
+            self._variant = _cabi.VARIANT_V3
+        else:
+            self._variant = _cabi.VARIANT_V2 if approximate_image2_gradient else _cabi.VARIANT_V1
         if weighting is None:
             weighting = "student_t_reference" if use_weighter else "none"
         if weighting not in _WEIGHTS:
@@ -207,6 +215,8 @@ class RobustDVOHIP:
         r, J, valid, uv, (h, w) = self._ctx.residuals_jacobian(level, self._prev_slot, self._cur_slot,
                                                                estimate.exp(), self._variant)
         mask = ~np.isnan(uv[:, 0])          # depth != 0 (camera_model.py:195); quirk Q6: not the in-bounds test
+        if self._variant == _cabi.VARIANT_V3:
+            mask = valid                    # the numba.cuda kernel writes mask = depth-valid AND in bounds (:103-109)
         residuals = r[valid].reshape(-1, 1)
         jacobian = J[valid]
         logger.debug("Intensity Residuals (min, max, mean): ({}, {}, {})".format(

@@ -241,23 +241,71 @@ class PairLevel:
     grady: Optional[np.ndarray] = None
 
 
+def residuals_and_jacobian_v3(lv: PairLevel, T: np.ndarray):
+    """The reference's numba.cuda backend: residuals_kernel (cuda/residuals_kernel.py:46-109) + the host-side
+    compaction of gpu_robust_dense_visual_odometry.py:118-120, restated with the arithmetic types numba infers for
+    that source: `tx - cx` is int32 - float32 = float64, so the back-projection, the rigid transform, the Jacobian
+    terms and the projection are float64 (stored / passed on as float32 where the kernel's signature says float32:
+    the Jacobian array, the arguments of the device function interpolate_bilinear); z = depth * depth_scale and the
+    central-difference gradient (compute_gradients, :8-19) are float32.  No FMA contraction is assumed.
+    PARITY UNPINNED: numba.cuda cannot run here and the reference holds no outputs of this kernel.
+
+    Returns r (N,1) f32, J (N,6) f32, mask (H,W) bool — for this variant the mask the kernel writes is
+    depth-valid AND strictly in bounds (x1 < W, y1 < H, :30-31), and equals `valid`."""
+    d = np.asarray(lv.depth_prev)
+    h, w = d.shape
+    fx, fy = np.float32(lv.KL[0, 0]), np.float32(lv.KL[1, 1])
+    cx, cy = np.float32(lv.KL[0, 2]), np.float32(lv.KL[1, 2])
+    T = np.asarray(T, dtype=np.float32)
+    R, tv = T[:3, :3], T[:3, 3]
+    mask0 = d != 0                                                            # :60-65
+    ty, tx = np.nonzero(mask0)
+    z = d[mask0].astype(np.float32) * np.float32(lv.depth_scale)              # :67  uint16 * float32 -> float32
+    z64 = z.astype(np.float64)
+    x = (tx.astype(np.float64) - np.float64(cx)) * z64 / np.float64(fx)       # :69-70 float64
+    y = (ty.astype(np.float64) - np.float64(cy)) * z64 / np.float64(fy)
+    R64, t64 = R.astype(np.float64), tv.astype(np.float64)
+    x1 = R64[0, 0] * x + R64[0, 1] * y + R64[0, 2] * z64 + t64[0]             # :73-75
+    y1 = R64[1, 0] * x + R64[1, 1] * y + R64[1, 2] * z64 + t64[1]
+    z1 = R64[2, 0] * x + R64[2, 1] * y + R64[2, 2] * z64 + t64[2]
+    g1x, g1y = central_diff(lv.gray_prev)                                     # :82-83 (float32 return)
+    gx = g1x[mask0].astype(np.float64)
+    gy = g1y[mask0].astype(np.float64)
+    fx64, fy64 = np.float64(fx), np.float64(fy)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        J = np.empty((z.shape[0], 6), dtype=np.float32)                       # :87-92, float64 expressions, float32 store
+        J[:, 0] = fx64 * gx / z1
+        J[:, 1] = fy64 * gy / z1
+        J[:, 2] = -fx64 * gx * x1 / (z1 ** 2) - fy64 * gy * y1 / (z1 ** 2)
+        J[:, 3] = -fx64 * gx * x1 * y1 / (z1 ** 2) - fy64 * gy * ((y1 ** 2 / z1 ** 2) + 1)
+        J[:, 4] = fx64 * gx * (x1 ** 2 / (z1 ** 2) + 1) + fy64 * gy * x1 * y1 / (z1 ** 2)
+        J[:, 5] = -fx64 * gx * y1 / z1 + fy64 * gy * x1 / z1
+        wx = (fx64 * x1 / z1 + np.float64(cx)).astype(np.float32)             # :95-96, then float32 argument of :99
+        wy = (fy64 * y1 / z1 + np.float64(cy)).astype(np.float32)
+        x0 = np.floor(wx)                                                     # x // 1
+        y0 = np.floor(wy)
+        inb = (x0 >= 0) & (y0 >= 0) & (x0 + 1 < w) & (y0 + 1 < h)             # :30-31 strict
+    i2 = bilinear(lv.gray_cur, np.where(inb, wx, np.float32(-1)), np.where(inb, wy, np.float32(-1)))
+    ok = ~np.isnan(i2)
+    r = (i2[ok] - lv.gray_prev[mask0][ok].astype(np.float32)).reshape(-1, 1).astype(np.float32)   # :108
+    valid = np.zeros((h, w), dtype=bool)
+    valid[ty[ok], tx[ok]] = True
+    return r, J[ok], valid, valid
+
+
 def residuals_and_jacobian(lv: PairLevel, T: np.ndarray, variant: str = VARIANT_V1):
     """compute_residuals_and_jacobian, cpu_robust...:134-200 (V1/V2) or the numba.cuda kernel
     cuda/residuals_kernel.py:46-109 + host compaction gpu_robust...:118-120 (V3).
 
     Returns r (N,1) f32, J (N,6) f32, mask (H,W) bool [depth-valid only for V1/V2 — quirk Q6],
     valid (H,W) bool [depth-valid AND in-bounds: the pixels r/J rows correspond to]."""
+    if variant == VARIANT_V3:
+        return residuals_and_jacobian_v3(lv, T)
     x, y, z, mask = deproject(lv.depth_prev, lv.KL, lv.depth_scale)
     xp, yp, zp = transform_points(T, x, y, z)
     u, v = project(lv.KL, xp, yp, zp)
     h, w = lv.gray_cur.shape
-    if variant == VARIANT_V3:
-        # strict rule of cuda/residuals_kernel.py:30-31: x1 >= W or y1 >= H invalid
-        with np.errstate(invalid="ignore"):
-            strict = (np.floor(u) >= 0) & (np.floor(v) >= 0) & (np.floor(u) + 1 < w) & (np.floor(v) + 1 < h)
-        i2 = bilinear(lv.gray_cur, np.where(strict, u, F32(-1)), v)
-    else:
-        i2 = bilinear(lv.gray_cur, u, v)
+    i2 = bilinear(lv.gray_cur, u, v)
     ok = ~np.isnan(i2)                                                   # :180
     i1 = lv.gray_prev[mask].astype(np.float32)
     r = (i2[ok] - i1[ok]).reshape(-1, 1).astype(np.float32)               # :191-194
@@ -273,11 +321,6 @@ def residuals_and_jacobian(lv: PairLevel, T: np.ndarray, variant: str = VARIANT_
         Jw = warp_jacobian(x[ok], y[ok], z[ok], lv.KL)                   # :63-68 then row filter :188
         gx = g1x[mask][ok]
         gy = g1y[mask][ok]
-    elif variant == VARIANT_V3:
-        g1x, g1y = central_diff(lv.gray_prev)                            # kernel :82-83
-        Jw = warp_jacobian(xp[ok], yp[ok], zp[ok], lv.KL)                # kernel :87-92 at p'
-        gx = g1x[mask][ok]
-        gy = g1y[mask][ok]
     else:
         raise ValueError(variant)
     J = (gx[:, None] * Jw[:, 0, :] + gy[:, None] * Jw[:, 1, :]).astype(np.float32)   # _fill_jacobian :79-90
@@ -285,8 +328,7 @@ def residuals_and_jacobian(lv: PairLevel, T: np.ndarray, variant: str = VARIANT_
     flat = valid.reshape(-1)
     idx = np.flatnonzero(mask.reshape(-1))
     flat[idx[ok]] = True
-    out_mask = valid if variant == VARIANT_V3 else mask
-    return r, J, out_mask, valid
+    return r, J, mask, valid
 
 
 # ================================================================================================

@@ -423,7 +423,7 @@ def test_error_codes(hip, frames):
         ctx.normal_equations(4, [0], [1], T)               # level not built
     assert e.value.code == -1
     with pytest.raises(dvo_amd.DVOHipError) as e:
-        ctx.normal_equations(0, [0], [1], T, variant=cabi.VARIANT_V3)
+        ctx.normal_equations(0, [0], [1], T, variant=7)
     assert e.value.code == -1
     with pytest.raises(dvo_amd.DVOHipError):
         ctx.normal_equations(0, [0] * 17, [1] * 17, np.repeat(T, 17, axis=0))      # > max_pairs
@@ -524,3 +524,39 @@ def test_projection_division_is_bit_identical_to_ieee(hip):
     a = np.array([100.0, 3.0, 1e-18, 5.0], dtype=np.float32)
     out, ref = ctx.debug_divide(a, b)
     assert np.array_equal(out[:3], ref[:3]) and not np.isfinite(out[3]) and not np.isfinite(ref[3])
+
+
+# ------------------------------------------------------------------------------------------------
+# variant V3: the reference's numba.cuda kernel semantics (parity unpinned: oracle restatement only)
+# ------------------------------------------------------------------------------------------------
+def test_variant_v3_dense_and_increments_vs_oracle(hip, frames, pyramids):
+    """cuda/residuals_kernel.py:46-109 restated with numba's arithmetic types (float64 geometry / Jacobian terms,
+    float32 stores) in both the oracle and the kernel: validity and J are bit-identical, r to float32 rounding."""
+    ctx, cabi = hip
+    for lvl, xi in ((2, [0.002, -0.007, -0.011, 0.005, 0.0065, 0.0034]), (1, [0, 0, 0, 0, 0, 0]), (3, [0.01, 0.004, -0.02, -0.01, 0.008, 0.015])):
+        T = O.Pose.from_xi(np.array(xi, dtype=np.float64)).matrix()
+        r, J, valid, uv, (h, w) = ctx.residuals_jacobian(lvl, 0, 1, T, variant=cabi.VARIANT_V3)
+        ro, Jo, mask_o, valid_o = O.residuals_and_jacobian(_level(frames, pyramids, 0, lvl), T, "v3")
+        assert np.array_equal(valid.reshape(h, w), valid_o)
+        assert np.array_equal(J[valid], Jo)                                # float64 expressions, float32 store: exact
+        np.testing.assert_allclose(r[valid], ro.reshape(-1), rtol=0, atol=1e-4)
+        rec = ctx.normal_equations(lvl, [0], [1], T[None], cabi.VARIANT_V3)[0]
+        H, b, swr2, n, _ = cabi.unpack_record(rec)
+        Ho, bo, so, no = O.normal_equations(ro, Jo)
+        assert n == no and _rel(H, Ho) < 1e-6 and _rel(_solve(H, b), O.solve_increment(Ho, bo)) < 1e-5
+
+
+def test_variant_v3_full_solve_vs_oracle(frames):
+    import dvo_amd
+    cam = dvo_amd.RGBDCameraModel(frames["K"], frames["depth_scale"])
+    est = O.gauss_newton(frames["gray"][0], frames["depth"][0], frames["gray"][1], frames["K"], frames["depth_scale"],
+                         levels=4, max_iterations=10, variant="v3")
+    for solver in ("host", "device"):
+        dvo = dvo_amd.get_dvo("robust-dvo", cam, dvo_amd.Se3.identity(), levels=4, max_iterations=10,
+                              reference_variant="cuda", solver=solver)
+        dvo.step_gray(frames["gray"][0], frames["depth"][0])
+        tf = dvo.step_gray(frames["gray"][1], frames["depth"][1])
+        np.testing.assert_allclose(tf.log().reshape(6), est.log(), rtol=0, atol=2e-6)
+    dvo._setup(0)
+    r, J, mask = dvo.compute_residuals_and_jacobian(dvo_amd.Se3.identity(), level=0)
+    assert mask.sum() == r.shape[0]          # this variant's mask is depth-valid AND in bounds

@@ -262,3 +262,32 @@ def test_gauss_newton_motion_prior_sequence(frames, golden_dir):
     # the prior matters at this sigma: the unconstrained solution is far away
     free = np.load(golden_dir / "pairs_l4.npz")["final_xi"][0]
     assert np.abs(free - g["final_xi"][0]).max() > 1e-3
+
+
+def test_variant_v3_strict_bounds_and_types(golden_dir, frames):
+    """V3 = the reference's numba.cuda kernel (cuda/residuals_kernel.py:46-109): parity unpinned (cannot run here);
+    these are the properties its source guarantees."""
+    t = np.load(golden_dir / "tiny10.npz")
+    K = np.zeros((3, 4), dtype=np.float32)
+    K[:3, :3] = np.eye(3)
+    lv = O.PairLevel(t["gray"], t["depth"], t["gray"], K, 1.0)
+    r, J, mask, valid = O.residuals_and_jacobian(lv, np.eye(4, dtype=np.float32), "v3")
+    # strict rule x1 < W, y1 < H (:30-31): the last row and column are invalid -> 9 x 9 pixels, mask == valid
+    assert r.shape == (81, 1) and np.all(r == 0) and mask.sum() == 81 and not mask[-1].any() and not mask[:, -1].any()
+    assert J.dtype == np.float32 and np.array_equal(mask, valid)
+    # central differences are 1/16 of the unnormalised Sobel response on a linear ramp; J_w at the warped point
+    ramp = np.tile((np.arange(64) * 3).astype(np.uint8), (48, 1))
+    gx, gy = O.central_diff(ramp)
+    sx, sy = O.sobel3(ramp)
+    assert np.all(gx[:, 1:-1] == 3.0) and np.all(sx[:, 1:-1] == 24.0) and np.all(gy == 0)
+    # on real data V3 and V1 agree on the residuals of the pixels both accept (same warp up to float32/float64 rounding)
+    gp, dp, gc = (O.build_pyramid(frames["gray"][0], 3), O.build_pyramid(frames["depth"][0], 3),
+                  O.build_pyramid(frames["gray"][1], 3))
+    lv = O.PairLevel(gp[2], dp[2], gc[2], O.level_intrinsics(frames["K"], 2), frames["depth_scale"])
+    T = O.Pose.from_xi(np.array([0.002, -0.007, -0.011, 0.005, 0.0065, 0.0034])).matrix()
+    r3, J3, m3, v3 = O.residuals_and_jacobian(lv, T, "v3")
+    r1, J1, m1, v1 = O.residuals_and_jacobian(lv, T, "v1")
+    both = v1 & v3
+    a = np.zeros(v1.shape, np.float32); a[v1] = r1.reshape(-1)
+    b = np.zeros(v3.shape, np.float32); b[v3] = r3.reshape(-1)
+    assert both.sum() > 0.95 * v1.sum() and np.abs(a[both] - b[both]).max() < 0.05
