@@ -71,6 +71,8 @@ struct dvo_ctx {
     int* d_iters = nullptr;
     double* d_err = nullptr;
     uint8_t* d_stage_img = nullptr;      // staging for host->device image uploads (bgr needs 3 B/px + depth)
+    uint8_t* d_batch_stage = nullptr;    // staging of dvo_upload_frames (whole batches), grown on demand
+    size_t batch_stage_bytes = 0;
     float* d_dense = nullptr;            // dense writer outputs: r[npix] J[6 npix] uv[2 npix] + valid
     double* d_trace = nullptr;
     int trace_cap = 0;
@@ -84,6 +86,7 @@ struct dvo_ctx {
     hipEvent_t ev_a = nullptr, ev_b = nullptr;
     hipEvent_t tm_a = nullptr, tm_b = nullptr;
     hipEvent_t ev_staging = nullptr;
+    hipEvent_t ev_order = nullptr;       // dvo_wait_for: marks "everything enqueued on this ctx so far"
     bool staging_in_flight = false;
     struct PendingEv { hipEvent_t a, b; int level; };
     std::vector<PendingEv> pending;
@@ -391,6 +394,7 @@ int dvo_create(int device, int max_w, int max_h, int max_levels, int n_slots, in
     CREATE_TRY(hipEventCreate(&ctx->tm_a));
     CREATE_TRY(hipEventCreate(&ctx->tm_b));
     CREATE_TRY(hipEventCreateWithFlags(&ctx->ev_staging, hipEventDisableTiming));
+    CREATE_TRY(hipEventCreateWithFlags(&ctx->ev_order, hipEventDisableTiming));
     CREATE_TRY(hipStreamSynchronize(ctx->stream));
     {
         const char* e = getenv("DVO_GRAPH");
@@ -412,8 +416,9 @@ void dvo_destroy(dvo_ctx* ctx)
     if (ctx->tm_a) (void)hipEventDestroy(ctx->tm_a);
     if (ctx->tm_b) (void)hipEventDestroy(ctx->tm_b);
     if (ctx->ev_staging) (void)hipEventDestroy(ctx->ev_staging);
+    if (ctx->ev_order) (void)hipEventDestroy(ctx->ev_order);
     void* dev[] = {ctx->d_slots, ctx->d_prev, ctx->d_cur, ctx->d_T, ctx->d_Tinit, ctx->d_wparam, ctx->d_active, ctx->d_partials,
-                   ctx->d_out, ctx->d_state, ctx->d_xi, ctx->d_iters, ctx->d_err, ctx->d_stage_img, ctx->d_dense, ctx->d_trace, ctx->d_frame_slots, ctx->d_prior};
+                   ctx->d_out, ctx->d_state, ctx->d_xi, ctx->d_iters, ctx->d_err, ctx->d_stage_img, ctx->d_dense, ctx->d_trace, ctx->d_frame_slots, ctx->d_prior, ctx->d_batch_stage};
     for (void* p : dev) if (p) (void)hipFree(p);
     void* host[] = {ctx->hs.prev, ctx->hs.cur, ctx->hs.T, ctx->hs.wparam, ctx->hs.out, ctx->hs.xi, ctx->hs.iters, ctx->hs.err, ctx->h_frame_slots, ctx->h_prior};
     for (void* p : host) if (p) (void)hipHostFree(p);
@@ -537,6 +542,57 @@ int dvo_upload_frames_device(dvo_ctx* ctx, int n_frames, const int* slots, const
     HIP_TRY(ctx, dvo_launch_batch_ingest(p, ctx->stream));
     for (int i = 0; i < n_frames; ++i) ctx->slots[slots[i]].ready = true;
     return DVO_OK;
+}
+
+int dvo_upload_frames(dvo_ctx* ctx, int n_frames, const int* slots, const uint8_t* gray, const uint16_t* depth,
+                      int w, int h, int levels)
+{
+    if (!ctx) return DVO_ERR_INVALID_ARG;
+    if (!slots || !gray || !depth) return fail(ctx, DVO_ERR_INVALID_ARG, "dvo_upload_frames: null argument");
+    if (n_frames < 1 || n_frames > ctx->n_slots) return fail(ctx, DVO_ERR_INVALID_ARG, "n_frames %d outside [1,%d]", n_frames, ctx->n_slots);
+    if (w <= 0 || h <= 0 || w > ctx->max_w || h > ctx->max_h) return fail(ctx, DVO_ERR_INVALID_ARG, "image %dx%d outside the ctx maximum", w, h);
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    // one device staging area for the whole batch (grown on demand), two large copies instead of 2 per frame
+    const size_t npx = (size_t)w * h, need = align_up(npx * n_frames, 256) + npx * n_frames * 2 + 256;
+    if (need > ctx->batch_stage_bytes) {
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        if (ctx->d_batch_stage) (void)hipFree(ctx->d_batch_stage);
+        ctx->d_batch_stage = nullptr;
+        ctx->batch_stage_bytes = 0;
+        HIP_TRY(ctx, hipMalloc((void**)&ctx->d_batch_stage, need));
+        ctx->batch_stage_bytes = need;
+    }
+    uint8_t* sg = ctx->d_batch_stage;
+    uint16_t* sd = reinterpret_cast<uint16_t*>(ctx->d_batch_stage + align_up(npx * n_frames, 256));
+    HIP_TRY(ctx, hipMemcpyAsync(sg, gray, npx * n_frames, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(sd, depth, npx * n_frames * 2, hipMemcpyHostToDevice, ctx->stream));
+    return dvo_upload_frames_device(ctx, n_frames, slots, sg, sd, w, h, levels);
+}
+
+int dvo_wait_for(dvo_ctx* ctx, dvo_ctx* other)
+{
+    if (!ctx || !other) return DVO_ERR_INVALID_ARG;
+    if (ctx == other) return DVO_OK;
+    if (ctx->device != other->device) return fail(ctx, DVO_ERR_INVALID_ARG, "dvo_wait_for: contexts are on different devices");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipEventRecord(other->ev_order, other->stream));
+    HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, other->ev_order, 0));
+    return DVO_OK;
+}
+
+int dvo_host_alloc(size_t bytes, void** out)
+{
+    if (!out || bytes == 0) return DVO_ERR_INVALID_ARG;
+    *out = nullptr;
+    hipError_t e = hipHostMalloc(out, bytes, hipHostMallocDefault);
+    if (e != hipSuccess) return fail(nullptr, (e == hipErrorOutOfMemory) ? DVO_ERR_OUT_OF_MEMORY : DVO_ERR_HIP, "hipHostMalloc(%zu): %s", bytes, hipGetErrorString(e));
+    return DVO_OK;
+}
+
+int dvo_host_free(void* p)
+{
+    if (!p) return DVO_OK;
+    return hipHostFree(p) == hipSuccess ? DVO_OK : DVO_ERR_HIP;
 }
 
 int dvo_upload_frame_bgr(dvo_ctx* ctx, int slot, const uint8_t* bgr, const uint16_t* depth, int w, int h, int levels,

@@ -45,6 +45,10 @@ SIGNATURES = {
     "dvo_upload_frame": (C.c_int, [_ctx, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int]),
     "dvo_upload_frame_device": (C.c_int, [_ctx, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int]),
     "dvo_upload_frames_device": (C.c_int, [_ctx, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int]),
+    "dvo_upload_frames": (C.c_int, [_ctx, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int]),
+    "dvo_wait_for": (C.c_int, [_ctx, _ctx]),
+    "dvo_host_alloc": (C.c_int, [C.c_size_t, C.POINTER(C.c_void_p)]),
+    "dvo_host_free": (C.c_int, [C.c_void_p]),
     "dvo_upload_frame_bgr": (C.c_int, [_ctx, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_double]),
     "dvo_download_level": (C.c_int, [_ctx, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "dvo_slot_info": (C.c_int, [_ctx, C.c_int, _c_int_p, _c_int_p, _c_int_p]),
@@ -160,6 +164,10 @@ class HipContext:
     def synchronize(self):
         self._check(self._lib.dvo_synchronize(self._h))
 
+    def wait_for(self, other: "HipContext"):
+        """Work enqueued on this ctx from now on waits (on the GPU) for everything enqueued on `other` so far."""
+        self._check(self._lib.dvo_wait_for(self._h, other._h))
+
     # -- camera -----------------------------------------------------------------------------------
     def set_camera(self, fx, fy, cx, cy, skew, depth_scale):
         self._check(self._lib.dvo_set_camera(self._h, float(fx), float(fy), float(cx), float(cy), float(skew),
@@ -188,6 +196,17 @@ class HipContext:
         sl = _as(slots, np.int32)
         self._check(self._lib.dvo_upload_frames_device(self._h, sl.shape[0], _ptr(sl), C.c_void_p(d_gray_ptr),
                                                        C.c_void_p(d_depth_ptr), w, h, levels))
+
+    def upload_frames(self, slots, gray: np.ndarray, depth: np.ndarray, levels: int):
+        """n frames from contiguous host arrays [n][h][w] (u8 gray, u16 depth).  Asynchronous when the arrays are
+        page-locked (`pinned_array`): keep them untouched until the next blocking call."""
+        sl = _as(slots, np.int32)
+        g = np.ascontiguousarray(gray, dtype=np.uint8)
+        d = np.ascontiguousarray(depth, dtype=np.uint16)
+        if g.ndim != 3 or g.shape != d.shape or g.shape[0] != sl.shape[0]:
+            raise ValueError("gray/depth must be [n][h][w] arrays matching the slot list")
+        self._keepalive = (g, d)
+        self._check(self._lib.dvo_upload_frames(self._h, sl.shape[0], _ptr(sl), _ptr(g), _ptr(d), g.shape[2], g.shape[1], levels))
 
     def upload_frame_bgr(self, slot: int, bgr: np.ndarray, depth: np.ndarray, levels: int, max_distance: float):
         c = _as(bgr, np.uint8)
@@ -344,6 +363,40 @@ class HipContext:
         ms = C.c_float()
         self._check(self._lib.dvo_timer_stop(self._h, C.byref(ms)))
         return float(ms.value)
+
+
+class _PinnedBuffer:
+    def __init__(self, nbytes: int):
+        self.ptr = C.c_void_p()
+        rc = lib().dvo_host_alloc(nbytes, C.byref(self.ptr))
+        if rc != 0:
+            raise DVOHipError(rc, "dvo_host_alloc failed")
+        self.nbytes = nbytes
+
+    def __del__(self):
+        try:
+            if self.ptr:
+                lib().dvo_host_free(self.ptr)
+                self.ptr = None
+        except Exception:
+            pass
+
+
+def pinned_array(shape, dtype) -> np.ndarray:
+    """NumPy array backed by page-locked host memory (dvo_host_alloc); freed when the array is collected."""
+    dt = np.dtype(dtype)
+    n = int(np.prod(shape)) * dt.itemsize
+    buf = _PinnedBuffer(max(n, 1))
+    raw = (C.c_uint8 * max(n, 1)).from_address(buf.ptr.value)
+    arr = np.frombuffer(raw, dtype=dt, count=int(np.prod(shape))).reshape(shape)
+    arr.flags.writeable = True
+    _PINNED[id(raw)] = buf                     # tie the allocation's lifetime to the ctypes buffer
+    import weakref
+    weakref.finalize(raw, _PINNED.pop, id(raw), None)
+    return arr
+
+
+_PINNED = {}
 
 
 def unpack_record(rec: np.ndarray):

@@ -54,11 +54,12 @@ class BatchAligner:
                                       self.levels)
 
     def ingest_host(self, gray: np.ndarray, depth: np.ndarray):
+        """[n][h][w] host arrays -> slots 0..n-1 in one batched upload (asynchronous for page-locked arrays, see
+        `_cabi.pinned_array`)."""
         n = gray.shape[0]
         if not (2 <= n <= self.max_pairs + 1):
             raise ValueError("n_frames must be in [2, {}]".format(self.max_pairs + 1))
-        for i in range(n):
-            self.ctx.upload_frame(int(self._slots[i]), gray[i], depth[i], self.levels)
+        self.ctx.upload_frames(self._slots[:n], gray, depth, self.levels)
 
     def solve_enqueue(self, n_frames: int, T_init: Optional[np.ndarray] = None):
         prev = self._slots[:n_frames - 1]
@@ -115,6 +116,21 @@ class StreamedAligner:
         sl = self._slices(n_frames)
         for a, lo, hi in sl:                                   # enqueue everything first, then fetch
             a.ingest_device(d_gray_ptr + lo * npx, d_depth_ptr + 2 * lo * npx, hi - lo + 1)
+            a.solve_enqueue(hi - lo + 1)
+        res = [a.solve_fetch(hi - lo + 1) for a, lo, hi in sl]
+        return {k: np.concatenate([r[k] for r in res], axis=0) for k in res[0]}
+
+    def align_host(self, gray: np.ndarray, depth: np.ndarray):
+        """Host frames [n][h][w] (ideally page-locked): the H2D copy of one slice overlaps the solve of another."""
+        n_frames = gray.shape[0]
+        sl = self._slices(n_frames)
+        prev = None
+        for a, lo, hi in sl:
+            if prev is not None:
+                a.ctx.wait_for(prev.ctx)        # uploads take turns on the PCIe link; each solve starts behind its own
+            a.ingest_host(gray[lo:hi + 1], depth[lo:hi + 1])
+            prev = a
+        for a, lo, hi in sl:
             a.solve_enqueue(hi - lo + 1)
         res = [a.solve_fetch(hi - lo + 1) for a, lo, hi in sl]
         return {k: np.concatenate([r[k] for r in res], axis=0) for k in res[0]}

@@ -34,6 +34,7 @@
 #ifndef DVO_HIP_H
 #define DVO_HIP_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -104,6 +105,18 @@ int dvo_upload_frame_device(dvo_ctx* ctx, int slot, const void* d_gray, const vo
  * launches per pyramid level for the whole batch (async on the ctx stream). */
 int dvo_upload_frames_device(dvo_ctx* ctx, int n_frames, const int* slots, const void* d_gray, const void* d_depth,
                              int w, int h, int levels);
+/* Batched form for HOST images: contiguous [n][h][w] arrays, two large H2D copies + the batched build.  With
+ * page-locked host memory (dvo_host_alloc) the copies are asynchronous: the arrays must then stay untouched until
+ * the next blocking call on this ctx (dvo_synchronize, dvo_solve_batch_fetch, ...). */
+int dvo_upload_frames(dvo_ctx* ctx, int n_frames, const int* slots, const uint8_t* gray, const uint16_t* depth,
+                      int w, int h, int levels);
+/* Stream ordering between two contexts of one GPU: work enqueued on `ctx` after this call starts only when
+ * everything enqueued on `other` so far has finished (event record + stream wait; nothing blocks on the host).
+ * Used to run the uploads of several contexts one after another on the PCIe link while their solves overlap. */
+int dvo_wait_for(dvo_ctx* ctx, dvo_ctx* other);
+/* Page-locked host memory for the upload paths (hipHostMalloc / hipHostFree). */
+int dvo_host_alloc(size_t bytes, void** out);
+int dvo_host_free(void* p);
 /* Colour ingest: BGR u8 [h][w][3] -> gray (OpenCV 8-bit fixed point) and depth clamp
  * depth*depth_scale > max_distance -> 0, on device (core/base_dense_visual_odometry.py:58-59). */
 int dvo_upload_frame_bgr(dvo_ctx* ctx, int slot, const uint8_t* bgr, const uint16_t* depth, int w, int h, int levels,

@@ -84,3 +84,27 @@ def test_config3_1280x960_five_levels_huber():
         gt = synthetic.relative_transform(st["T_wc"][k], st["T_wc"][k + 1])
         assert np.abs(res["T"][k] - gt[:3]).max() < 2e-3
         assert res["iters"][k] > 25
+
+
+def test_batched_host_upload_and_streamed_aligner(vga_stream):
+    """dvo_upload_frames (two large H2D copies, page-locked memory) + StreamedAligner.align_host == per-pair results."""
+    from dvo_amd import _cabi
+    from dvo_amd.batch import BatchAligner, StreamedAligner
+    st = vga_stream
+    g = _cabi.pinned_array(st["gray"].shape, np.uint8)
+    d = _cabi.pinned_array(st["depth"].shape, np.uint16)
+    g[...] = st["gray"]
+    d[...] = st["depth"]
+    ref = BatchAligner(st["K"], st["depth_scale"], 640, 480, 4, max_pairs=8, max_iterations=10)
+    r0 = ref.align_host(st["gray"], st["depth"])
+    lvl2 = ref.ctx.download_level(3, 2)
+    ref.close()
+    sa = StreamedAligner(st["K"], st["depth_scale"], 640, 480, 4, max_pairs=8, n_streams=2, max_iterations=10)
+    r1 = sa.align_host(g, d)
+    got = sa.parts[0].ctx.download_level(3, 2)
+    sa.close()
+    for k in ("gray", "depth", "gx", "gy"):
+        assert np.array_equal(got[k], lvl2[k])
+    assert r1["xi"].shape == (8, 6)
+    # slices of 4 pairs per stream vs one batch of 8: same data, at most last-bit differences (lane grouping)
+    np.testing.assert_allclose(r1["xi"], r0["xi"], rtol=0, atol=1e-9)
