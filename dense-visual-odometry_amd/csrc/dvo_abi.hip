@@ -275,7 +275,10 @@ int fill_reduce_params(dvo_ctx* ctx, int level, int n_pairs, int w, int h, DvoRe
         int gmax = 16;
         const char* e = getenv("DVO_MAX_GROUPS");
         if (e && atoi(e) > 0) gmax = atoi(e);
-        int gp = (int)(total_groups / 4096);
+        int target = 4096;
+        const char* tb = getenv("DVO_TARGET_BLOCKS");
+        if (tb && atoi(tb) > 0) target = atoi(tb);
+        int gp = (int)(total_groups / target);
         if (gp < 1) gp = 1;
         if (gp > gmax) gp = gmax;
         p->groups_per_block = gp;
@@ -334,6 +337,9 @@ int dvo_create(int device, int max_w, int max_h, int max_levels, int n_slots, in
     *out = nullptr;
     if (max_w <= 0 || max_h <= 0 || max_levels < 1 || max_levels > DVO_MAX_LEVELS || n_slots < 2 || max_pairs < 1)
         return fail(nullptr, DVO_ERR_INVALID_ARG, "dvo_create: bad sizes (max %dx%d, levels %d, slots %d, pairs %d)", max_w, max_h, max_levels, n_slots, max_pairs);
+    // the kernels form tap offsets y * pitch + x in float32 and pack pixel coordinates in 16 bits
+    if ((double)(max_h + 1) * (double)align_up((size_t)max_w + 2, 16) >= 16777216.0 || max_w > 65535 || max_h > 65535)
+        return fail(nullptr, DVO_ERR_INVALID_ARG, "dvo_create: %dx%d exceeds the supported image size ((h+1)*pitch must stay below 2^24)", max_w, max_h);
     int ndev = 0;
     hipError_t e = hipGetDeviceCount(&ndev);
     if (e != hipSuccess || ndev <= 0) return fail(nullptr, DVO_ERR_NO_DEVICE, "dvo_create: no HIP device (%s); there is no CPU fallback", hipGetErrorString(e));

@@ -47,6 +47,15 @@ def test_no_cpu_fallback_without_device():
         dvo_amd.get_dvo("kerl", cam, dvo_amd.Se3.identity(), levels=1)
 
 
+def test_create_rejects_bad_sizes_before_touching_the_device():
+    import dvo_amd
+    for kw in (dict(max_w=0), dict(max_h=-1), dict(max_levels=0), dict(max_levels=9), dict(n_slots=1), dict(max_pairs=0),
+               dict(max_w=8192, max_h=4096)):          # (h+1)*pitch >= 2^24: float32 tap offsets would be inexact
+        with pytest.raises(dvo_amd.DVOHipError) as e:
+            dvo_amd.HipContext(**kw)
+        assert e.value.code == -1, kw
+
+
 def test_product_package_does_not_import_the_oracle():
     pkg = ROOT / "dense-visual-odometry_amd"
     pat = re.compile(r"^\s*(import|from)\s+\S*oracle", re.M)
