@@ -87,6 +87,26 @@ def cpu_baseline(stream_np, levels, iterations, n_pairs):
                       "%.1f s; host has %d logical CPUs" % (n_pairs, levels, iterations, dt, os.cpu_count() or 0)}
 
 
+def fixture_ate(device):
+    """"ATE vs ref" part of the metric on the only real TUM data in the repo: the reference's 10-frame fr1/xyz
+    excerpt (tests/golden/frames.npz) through the HIP path, next to the ATE of the reference run's own trajectory
+    (tests/golden/sequence.npz, produced by oracle/refrun/make_golden.py)."""
+    import numpy as np
+    from dvo_amd.batch import BatchAligner, compose_trajectory, absolute_trajectory_error
+    try:
+        f = np.load(ROOT / "tests" / "golden" / "frames.npz")
+        ref = np.load(ROOT / "tests" / "golden" / "sequence.npz")
+    except Exception:
+        return None
+    al = BatchAligner(f["intrinsics"], float(f["depth_scale"]), 640, 480, 4, max_pairs=9, device=device, max_iterations=10)
+    res = al.align_host(f["gray"], f["depth"])
+    al.close()
+    traj = compose_trajectory(res["T"], init_pose=f["gt_T"][0])
+    return {"sequence": "TUM fr1/xyz, first 10 frames (reference tests/test_data), 4 levels x 10 iterations",
+            "ate_rmse_m": absolute_trajectory_error(traj, f["gt_T"]),
+            "reference_ate_rmse_m": absolute_trajectory_error(ref["pose_T"].astype(np.float64), f["gt_T"])}
+
+
 def main():
     args = parse_args()
     import numpy as np
@@ -185,7 +205,8 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32 per-pixel math, f64 accumulation/solve",
+            "dtype": "f32",
+            "dtype_note": "float32 per-pixel arithmetic (as the reference), float64 accumulation and 6x6 solve",
             "data": "synthetic",
             "config": {"workload": "synthetic %dx%d RGB-D stream, %d-level pyramid, %d GN iterations/level, "
                                    "%d frame pairs per GPU per step (pyramid+Sobel build and device-side GN solve "
@@ -205,6 +226,7 @@ def main():
                          "achieved_layout_GBs": layout_bytes / (avg_ms * 1e-3) / 1e9,
                          "valid_fraction_level0": valid_l0 / P0, "per_level": per_level},
         }
+        out["accuracy"] = fixture_ate(local_rank)
         if not args.no_cpu_baseline:
             cpu_frames = min(args.cpu_pairs + 1, n_frames)
             st_np = {"gray": gray[:cpu_frames].cpu().numpy(),
