@@ -560,3 +560,23 @@ def test_variant_v3_full_solve_vs_oracle(frames):
     dvo._setup(0)
     r, J, mask = dvo.compute_residuals_and_jacobian(dvo_amd.Se3.identity(), level=0)
     assert mask.sum() == r.shape[0]          # this variant's mask is depth-valid AND in bounds
+
+
+def test_degenerate_poses_give_empty_systems(hip):
+    """NaN / far-away / behind-the-camera poses: every pixel fails the in-bounds test, nothing is read out of bounds,
+    the record is exactly zero and the device loop stops after one iteration without touching the pose."""
+    ctx, cabi = hip
+    I = np.eye(4, dtype=np.float32)
+    Tnan = I.copy(); Tnan[0, 3] = np.nan
+    Tfar = I.copy(); Tfar[0, 3] = 1e6
+    Tbehind = I.copy(); Tbehind[2, 3] = -100.0
+    Tflip = np.diag([1, -1, -1, 1]).astype(np.float32)          # looks backwards: z' < 0, coordinates mirror
+    for T in (Tnan, Tfar):
+        rec = ctx.normal_equations(1, [0], [1], T[None])[0]
+        assert (rec == 0).all()
+    for T in (Tbehind, Tflip):                                   # the reference does not test z' > 0 either (quirk kept)
+        rec = ctx.normal_equations(1, [0], [1], T[None])[0]
+        assert np.isfinite(rec).all()
+    res = ctx.solve_batch([0], [1], levels=4, max_iterations=10, T_init=Tfar[None])
+    assert res["iters"][0] == 4                                  # one evaluated iteration per level, each stops at once
+    np.testing.assert_array_equal(res["T"][0], Tfar[:3])
