@@ -226,8 +226,9 @@ def main():
                          "achieved_layout_GBs": layout_bytes / (avg_ms * 1e-3) / 1e9,
                          "valid_fraction_level0": valid_l0 / P0, "per_level": per_level},
         }
-        out["accuracy"] = fixture_ate(local_rank)
-        if not args.no_cpu_baseline:
+        if world == 1:
+            out["accuracy"] = fixture_ate(local_rank)
+        if not args.no_cpu_baseline and world == 1:            # CPU baseline: rank 0 at N=1 only
             cpu_frames = min(args.cpu_pairs + 1, n_frames)
             st_np = {"gray": gray[:cpu_frames].cpu().numpy(),
                      "depth": depth[:cpu_frames].cpu().numpy().view(np.uint16),
