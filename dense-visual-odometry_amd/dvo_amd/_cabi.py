@@ -66,6 +66,11 @@ SIGNATURES = {
     "dvo_solve_batch_fetch": (C.c_int, [_ctx, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "dvo_debug_divide": (C.c_int, [_ctx, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]),
     "dvo_set_prior": (C.c_int, [_ctx, C.c_double, C.c_void_p, C.c_int]),
+    "dvo_comm_unique_id": (C.c_int, [C.c_void_p]),
+    "dvo_comm_create": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_void_p)]),
+    "dvo_allgather_poses": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
+    "dvo_comm_destroy": (None, [C.c_void_p]),
+    "dvo_comm_last_error": (C.c_char_p, []),
     "dvo_trace_enable": (C.c_int, [_ctx, C.c_int]),
     "dvo_trace_read": (C.c_int, [_ctx, C.c_int, C.c_void_p]),
     "dvo_profile_enable": (C.c_int, [_ctx, C.c_int]),
@@ -363,6 +368,47 @@ class HipContext:
         ms = C.c_float()
         self._check(self._lib.dvo_timer_stop(self._h, C.byref(ms)))
         return float(ms.value)
+
+
+class RcclPoseGather:
+    """RCCL all-gather of pose records through the C ABI (dvo_comm_*): for hosts without torch.distributed.
+    Rank 0 calls `RcclPoseGather.unique_id()` and ships the 128 bytes to the other ranks (file, socket, MPI...)."""
+
+    @staticmethod
+    def unique_id() -> bytes:
+        buf = C.create_string_buffer(128)
+        rc = lib().dvo_comm_unique_id(buf)
+        if rc != 0:
+            raise DVOHipError(rc, (lib().dvo_comm_last_error() or b"").decode())
+        return buf.raw
+
+    def __init__(self, device: int, rank: int, nranks: int, unique_id: bytes):
+        self._lib = lib()
+        self._h = C.c_void_p()
+        self.rank, self.nranks = rank, nranks
+        rc = self._lib.dvo_comm_create(device, rank, nranks, C.c_char_p(unique_id), C.byref(self._h))
+        if rc != 0:
+            raise DVOHipError(rc, (self._lib.dvo_comm_last_error() or b"").decode())
+
+    def allgather(self, records: np.ndarray) -> np.ndarray:
+        """(n,16) float32 records of this rank -> (nranks*n, 16), rank-major (n must be equal on all ranks)."""
+        rec = _as(records, np.float32).reshape(-1, 16)
+        out = np.empty((self.nranks * rec.shape[0], 16), dtype=np.float32)
+        rc = self._lib.dvo_allgather_poses(self._h, _ptr(rec), rec.shape[0], _ptr(out))
+        if rc != 0:
+            raise DVOHipError(rc, (self._lib.dvo_comm_last_error() or b"").decode())
+        return out
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.dvo_comm_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 class _PinnedBuffer:

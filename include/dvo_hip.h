@@ -178,6 +178,19 @@ int dvo_trace_read(dvo_ctx* ctx, int n_pairs, double* out /* n_pairs x cap x DVO
  * correction steps), ref[i] = the compiler's IEEE division on the device.  Host arrays of n floats. */
 int dvo_debug_divide(dvo_ctx* ctx, const float* a, const float* b, float* out, float* ref, int n);
 
+/* ---- multi-GPU: the one collective of the path -------------------------------------------
+ * One process per GPU; after a round every rank contributes n_records pose records of 16 floats (12 floats [R|t],
+ * iterations, final error, 2 reserved) and receives all ranks' records in rank order: one RCCL all-gather over
+ * xGMI (64 B per record: latency-bound).  RCCL is loaded with dlopen at first use.  No counterpart in the reference
+ * (it has no distributed code); Python hosts may equally use torch.distributed (dvo_amd.batch.allgather_poses). */
+typedef struct dvo_comm dvo_comm;
+int dvo_comm_unique_id(void* id128 /* 128 bytes out: rank 0 creates it and ships it to the other ranks */);
+int dvo_comm_create(int device, int rank, int nranks, const void* id128, dvo_comm** out);
+int dvo_allgather_poses(dvo_comm* comm, const float* mine /* n_records x 16 */, int n_records,
+                        float* all /* nranks x n_records x 16 */);
+void dvo_comm_destroy(dvo_comm* comm);
+const char* dvo_comm_last_error(void);
+
 /* ---- measurement ------------------------------------------------------------------------------- */
 
 /* When enabled, every launch of the reduction kernel is bracketed by HIP events on the ctx stream. */

@@ -108,3 +108,17 @@ def test_batched_host_upload_and_streamed_aligner(vga_stream):
     assert r1["xi"].shape == (8, 6)
     # slices of 4 pairs per stream vs one batch of 8: same data, at most last-bit differences (lane grouping)
     np.testing.assert_allclose(r1["xi"], r0["xi"], rtol=0, atol=1e-9)
+
+
+def test_rccl_pose_gather_through_the_c_abi():
+    """dvo_comm_* (RCCL via dlopen): world of one rank on the test box — unique id, communicator, all-gather."""
+    from dvo_amd import _cabi
+    uid = _cabi.RcclPoseGather.unique_id()
+    assert len(uid) == 128
+    comm = _cabi.RcclPoseGather(device=0, rank=0, nranks=1, unique_id=uid)
+    rec = np.arange(5 * 16, dtype=np.float32).reshape(5, 16)
+    out = comm.allgather(rec)
+    assert np.array_equal(out, rec)
+    out = comm.allgather(rec[:2] * 3)
+    assert np.array_equal(out, rec[:2] * 3)
+    comm.close()
