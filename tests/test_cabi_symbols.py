@@ -63,3 +63,32 @@ def test_product_package_does_not_import_the_oracle():
         assert not pat.search(path.read_text()), path
     for path in list(pkg.rglob("*.hip")) + list(pkg.rglob("*.h")):
         assert not re.search(r"#include\s+[\"<][^\">]*oracle", path.read_text()), path
+
+
+def test_header_is_plain_c(tmp_path):
+    """include/dvo_hip.h must be consumable by a C compiler (the boundary is a C ABI, not a C++ one) and a C program
+    must link against the shared library with nothing but the header."""
+    import shutil
+    import subprocess
+    if shutil.which("gcc") is None:
+        pytest.skip("gcc not available")
+    from dvo_amd import _cabi
+    src = tmp_path / "use_abi.c"
+    src.write_text(
+        '#include "dvo_hip.h"\n#include <stdio.h>\n'
+        "int main(void) {\n"
+        "    dvo_ctx* ctx = 0;\n"
+        "    int rc = dvo_create(0, 64, 48, 2, 2, 1, &ctx);\n"
+        '    printf("%d %s\\n", rc, dvo_last_error(0));\n'
+        "    if (rc == DVO_OK) dvo_destroy(ctx);\n"
+        "    return 0;\n}\n")
+    exe = tmp_path / "use_abi"
+    lib_dir = _cabi.library_path().parent
+    cmd = ["gcc", "-std=c99", "-Wall", "-Werror", "-pedantic", "-I", str(ROOT / "include"), str(src), "-o", str(exe),
+           "-L", str(lib_dir), "-l:libdvo_hip.so", "-Wl,-rpath," + str(lib_dir), "-Wl,--allow-shlib-undefined"]
+    out = subprocess.run(cmd, capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr
+    run = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
+    assert run.returncode == 0, run.stderr
+    code = int(run.stdout.split()[0])
+    assert code in (0, -2, -3)          # created (GPU box) or "no HIP device" (build container) — never a crash
