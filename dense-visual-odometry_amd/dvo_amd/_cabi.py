@@ -448,8 +448,18 @@ _PINNED = {}
 def unpack_record(rec: np.ndarray):
     """(32,) record -> H (6,6), b (6,) [already negated: b = -J^T W r], sum_wr2, n, sum_r2."""
     rec = np.asarray(rec, dtype=np.float64)
-    H = np.zeros((6, 6), dtype=np.float64)
-    iu = np.triu_indices(6)
-    H[iu] = rec[:21]
-    H = H + H.T - np.diag(np.diag(H))
+    H = rec[_FULL_FROM_TRIU]                       # (6,6) gather of the 21 upper-triangle entries
     return H, -rec[21:27], float(rec[27]), int(round(rec[28])), float(rec[29])
+
+
+def _full_from_triu():
+    idx = np.zeros((6, 6), dtype=np.intp)
+    q = 0
+    for i in range(6):
+        for j in range(i, 6):
+            idx[i, j] = idx[j, i] = q
+            q += 1
+    return idx
+
+
+_FULL_FROM_TRIU = _full_from_triu()
