@@ -469,6 +469,10 @@ int dvo_set_camera(dvo_ctx* ctx, float fx, float fy, float cx, float cy, float s
         volatile float z = ph + tl;
         if (!(z == ref)) ctx->z_fast = 0;
     }
+    {
+        const char* e = getenv("DVO_Z_FLOAT64");           // tests: force the float64 conversion path
+        if (e && e[0] == '1') ctx->z_fast = 0;
+    }
     ctx->have_camera = true;
     return DVO_OK;
 }

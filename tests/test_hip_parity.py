@@ -580,3 +580,82 @@ def test_degenerate_poses_give_empty_systems(hip):
     res = ctx.solve_batch([0], [1], levels=4, max_iterations=10, T_init=Tfar[None])
     assert res["iters"][0] == 4                                  # one evaluated iteration per level, each stops at once
     np.testing.assert_array_equal(res["T"][0], Tfar[:3])
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2, 3, 4, 5])
+def test_fuzz_random_geometry_vs_oracle(seed):
+    """Random image sizes (odd, not multiples of 4 or 64), intrinsics with and without skew, depth scales for which the
+    float32 double-word depth conversion is / is not exact, random poses and weights: validity and warped coordinates
+    bit-exact, normal equations and increments within tolerance, against the oracle."""
+    import dvo_amd
+    from dvo_amd import _cabi
+    rng = np.random.default_rng(100 + seed)
+    h = int(rng.integers(17, 150))
+    w = int(rng.integers(17, 210))
+    levels = int(rng.integers(1, 4))
+    while (min(h, w) >> (levels - 1)) < 4:
+        levels -= 1
+    yy, xx = np.mgrid[0:h, 0:w].astype(np.float32)
+    tex = 120 + 70 * np.sin(xx * rng.uniform(0.1, 0.5)) * np.cos(yy * rng.uniform(0.1, 0.5)) + rng.normal(0, 6, (h, w))
+    g1 = np.clip(tex, 0, 255).astype(np.uint8)
+    g2 = np.clip(np.roll(tex, int(rng.integers(-2, 3)), axis=1) + rng.normal(0, 3, (h, w)), 0, 255).astype(np.uint8)
+    depth = rng.integers(2000, 30000, size=(h, w)).astype(np.uint16)
+    depth[rng.random((h, w)) < rng.uniform(0.0, 0.6)] = 0
+    depth_scale = [0.0002, 1.0 / 5000.0, 0.001, 1.0 / 3.0e4, float(rng.uniform(1e-4, 1e-3)), 1.0][seed]
+    skew = 0.0 if seed % 2 == 0 else float(rng.uniform(-3, 3))
+    K = np.array([[rng.uniform(0.7, 1.4) * w, skew, w / 2 + rng.uniform(-5, 5)],
+                  [0, rng.uniform(0.7, 1.4) * w, h / 2 + rng.uniform(-5, 5)], [0, 0, 1]], dtype=np.float32)
+    with dvo_amd.HipContext(max_w=w, max_h=h, max_levels=levels, n_slots=2, max_pairs=1) as ctx:
+        ctx.set_camera(K[0, 0], K[1, 1], K[0, 2], K[1, 2], K[0, 1], depth_scale)
+        ctx.upload_frame(0, g1, depth, levels)
+        ctx.upload_frame(1, g2, depth, levels)
+        gp, dp, gc = O.build_pyramid(g1, levels), O.build_pyramid(depth, levels), O.build_pyramid(g2, levels)
+        for lvl in range(levels):
+            xi = rng.normal(0, 1, 6) * np.array([0.02, 0.02, 0.02, 0.01, 0.01, 0.01])
+            T = O.Pose.from_xi(xi).matrix()
+            lv = O.PairLevel(gp[lvl], dp[lvl], gc[lvl], O.level_intrinsics(K, lvl), depth_scale)
+            assert np.array_equal(ctx.level_intrinsics(lvl), lv.KL)
+            for variant, vname in ((_cabi.VARIANT_V1, "v1"), (_cabi.VARIANT_V2, "v2"), (_cabi.VARIANT_V3, "v3")):
+                if vname == "v3" and skew != 0.0:
+                    continue                                   # the numba.cuda kernel has no skew term at all
+                r, J, valid, uv, (hh, ww) = ctx.residuals_jacobian(lvl, 0, 1, T, variant=variant)
+                ro, Jo, _, valid_o = O.residuals_and_jacobian(lv, T, vname)
+                assert np.array_equal(valid.reshape(hh, ww), valid_o), (vname, lvl)
+                if vname == "v1":
+                    x, y, z, m = O.deproject(lv.depth_prev, lv.KL, lv.depth_scale)
+                    uo, vo = O.project(lv.KL, *O.transform_points(T, x, y, z))
+                    assert np.array_equal(uv[m.reshape(-1), 0], uo, equal_nan=True)
+                    assert np.array_equal(uv[m.reshape(-1), 1], vo, equal_nan=True)
+                if ro.shape[0] == 0:
+                    continue
+                np.testing.assert_allclose(r[valid], ro.reshape(-1), rtol=0, atol=2e-4)
+                scale = np.maximum(np.abs(Jo).max(axis=0), 1e-6)
+                np.testing.assert_allclose(J[valid] / scale, Jo / scale, rtol=0, atol=4e-6)
+                w_mode, w_par, w_or = _cabi.WEIGHT_NONE, None, None
+                if seed % 3 == 1:
+                    k = 1.345 * float(np.sqrt(np.mean(ro.astype(np.float64) ** 2)))
+                    w_mode, w_par, w_or = _cabi.WEIGHT_HUBER, [k], O.huber_weights(ro, float(np.float32(k)))
+                rec = ctx.normal_equations(lvl, [0], [1], T[None], variant, w_mode, w_par)[0]
+                H, b, swr2, n, sr2 = _cabi.unpack_record(rec)
+                Ho, bo, so, no = O.normal_equations(ro, Jo, w_or)
+                assert n == no
+                assert _rel(H, Ho) < 2e-6 and abs(swr2 - so) <= 2e-6 * max(so, 1e-9)
+                if no > 200 and np.linalg.cond(Ho) < 1e8:
+                    assert _rel(_solve(H, b), O.solve_increment(Ho, bo)) < 1e-4 * max(1.0, np.linalg.cond(Ho) / 1e4)
+
+
+def test_float64_depth_conversion_path_matches_fast_path(frames, monkeypatch):
+    """The exact float32 depth conversion is only enabled after an exhaustive host check; the float64 fallback
+    (forced here) must give bit-identical records."""
+    import dvo_amd
+    T = O.Pose.from_xi(np.array([0.002, -0.007, -0.011, 0.005, 0.0065, 0.0034])).matrix()[None]
+    recs = []
+    for force in ("0", "1"):
+        monkeypatch.setenv("DVO_Z_FLOAT64", force)
+        with dvo_amd.HipContext(max_w=640, max_h=480, max_levels=2, n_slots=2, max_pairs=1) as ctx:
+            K = frames["K"]
+            ctx.set_camera(K[0, 0], K[1, 1], K[0, 2], K[1, 2], K[0, 1], frames["depth_scale"])
+            ctx.upload_frame(0, frames["gray"][0], frames["depth"][0], 2)
+            ctx.upload_frame(1, frames["gray"][1], frames["depth"][1], 2)
+            recs.append(ctx.normal_equations(1, [0], [1], T))
+    assert np.array_equal(recs[0], recs[1])
