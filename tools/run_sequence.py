@@ -38,7 +38,18 @@ def main():
     args = ap.parse_args()
 
     from dvo_amd import synthetic, tum, RGBDCameraModel
-    from dvo_amd.batch import BatchAligner, compose_trajectory
+    from dvo_amd.batch import BatchAligner, compose_trajectory, shard_pairs, pose_records, allgather_poses
+
+    # BASELINE config 4: under torchrun (one process per GPU) the pairs of the sequence are split into contiguous
+    # ranges, one per rank; the pose records are all-gathered over RCCL and rank 0 composes / writes the trajectory.
+    import os
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 or os.environ.get("DVO_FORCE_DIST") == "1":
+        import torch
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
 
     gray_mode = True
     if args.fixture:
@@ -57,11 +68,17 @@ def main():
         scale = cam.depth_scale if cam else synthetic.DEPTH_SCALE
         frames, gt, stamps, kind, gray_mode = tum.iter_frames(seq), seq.gt_T_wc, seq.timestamps, "TUM", False
 
+    n_total = None
+    if world > 1 or os.environ.get("DVO_FORCE_DIST") == "1":
+        frames = list(frames)                      # (a rank only needs its own range; kept simple here)
+        n_total = len(frames)
+        lo, hi = shard_pairs(n_total - 1, rank, world)
+        frames = frames[lo:hi + 1]                 # pairs lo..hi-1 need frames lo..hi (one duplicated boundary frame)
     frames = iter(frames)
     first = next(frames)
     h, w = first[1].shape
     al = BatchAligner(K, scale, w, h, args.levels, max_pairs=args.window, max_iterations=args.iterations,
-                      weighting=args.weighting)
+                      weighting=args.weighting, device=local_rank)
     T_rel, iters, t_solve, n_frames = [], [], 0.0, 1
     carry = first
     done = False
@@ -90,6 +107,17 @@ def main():
         carry = batch[-1]
     al.close()
     T_rel = np.concatenate(T_rel)
+    if n_total is not None:
+        import torch.distributed as dist
+        counts = [shard_pairs(n_total - 1, r, world)[1] - shard_pairs(n_total - 1, r, world)[0] for r in range(world)]
+        rec = allgather_poses(pose_records(T_rel, np.concatenate(iters)), counts, device="cuda")
+        T_rel = rec[:, :12].reshape(-1, 3, 4)
+        iters = [rec[:, 12]]
+        n_frames = n_total
+        dist.barrier()
+        if rank != 0:
+            dist.destroy_process_group()
+            return
     init = gt[0] if gt is not None else np.eye(4)
     traj = compose_trajectory(T_rel, init_pose=init)
 
@@ -106,6 +134,9 @@ def main():
         json.dump(report, fp, indent=1)
     tum.write_tum_trajectory(args.out / "report.txt", stamps[:len(traj)], traj)
     print(json.dumps({k: v for k, v in report.items() if not isinstance(v, list)}))
+    if n_total is not None:
+        import torch.distributed as dist
+        dist.destroy_process_group()
 
 
 if __name__ == "__main__":
