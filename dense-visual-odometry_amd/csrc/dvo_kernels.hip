@@ -231,7 +231,7 @@ struct PixelOut {
 
 // Phase A of a pixel: geometry up to the in-bounds decision and the tap address (no dependent loads).
 struct PixelGeo {
-    float x, y, z;       // back-projected point (un-warped)
+    float x, y, z;       // back-projected point (un-warped) as (x/z, y/z, z): x/z, y/z are the normalised pixel coordinates
     float uw, vw;        // warped pixel coordinates
     unsigned off;        // offset of tap (y0, x0) in the packed plane (0 when !ok, so the load is harmless)
     bool ok;             // depth != 0 && warped point inside the closed image rectangle
@@ -278,6 +278,9 @@ __device__ __forceinline__ float dvo_div_with_rcp(float a, float b, float rb)
     return fmaf(e1, rb, q1);
 }
 
+// SKEW = false: the camera matrix has no skew term (K[0][1] == 0), so the zero products of the reference's matrix
+// expressions are skipped: x + (+-0) == x, exact.
+template <bool SKEW>
 __device__ __forceinline__ void dvo_geo(const DvoLevelGeom& g, const DvoLevelCam& cam, double depth_scale,
                                         const float* __restrict__ T, int ux, int vy, unsigned d, PixelGeo& o)
 {
@@ -289,7 +292,7 @@ __device__ __forceinline__ void dvo_geo(const DvoLevelGeom& g, const DvoLevelCam
     // --- deproject (camera_model.py:195-221) -------------------------------------------------------
     const float z = dvo_depth_to_z(d, depth_scale, cam);
     const float u = (float)ux, v = (float)vy;
-    const float xn = cam.skew0 ? ((cam.ia * u) + cam.ic) : (((cam.ia * u) + (cam.ib * v)) + cam.ic);   // ib == 0: + 0 is exact
+    const float xn = SKEW ? (((cam.ia * u) + (cam.ib * v)) + cam.ic) : ((cam.ia * u) + cam.ic);
     const float yn = (cam.id * v) + cam.ie;
     const float x = xn * z;
     const float y = yn * z;
@@ -297,7 +300,7 @@ __device__ __forceinline__ void dvo_geo(const DvoLevelGeom& g, const DvoLevelCam
     const float xp = ((T[0] * x + T[1] * y) + T[2] * z) + T[3];
     const float yp = ((T[4] * x + T[5] * y) + T[6] * z) + T[7];
     const float zp = ((T[8] * x + T[9] * y) + T[10] * z) + T[11];
-    const float un = cam.skew0 ? ((cam.fx * xp) + (cam.cx * zp)) : (((cam.fx * xp) + (cam.s * yp)) + (cam.cx * zp));
+    const float un = SKEW ? (((cam.fx * xp) + (cam.s * yp)) + (cam.cx * zp)) : ((cam.fx * xp) + (cam.cx * zp));
     const float vn = (cam.fy * yp) + (cam.cy * zp);
     // Correctly rounded quotients.  This is exactly the arithmetic core of the compiler's IEEE float32 division
     // (v_rcp_f32, two Newton steps on the reciprocal/quotient, final fma) without the v_div_scale / v_div_fixup
@@ -310,8 +313,8 @@ __device__ __forceinline__ void dvo_geo(const DvoLevelGeom& g, const DvoLevelCam
     const float uw = dvo_div_with_rcp(un, zp, rz);
     const float vw = dvo_div_with_rcp(vn, zp, rz);
     // closed-boundary rule: valid <=> 0 <= x <= W-1 and 0 <= y <= H-1 ; NaN compares false
-    const bool ok = (uw >= 0.0f) && (uw <= (float)(g.w - 1)) && (vw >= 0.0f) && (vw <= (float)(g.h - 1));
-    o.x = x; o.y = y; o.z = z; o.uw = uw; o.vw = vw; o.ok = ok;
+    const bool ok = (uw >= 0.0f) & (uw <= (float)(g.w - 1)) & (vw >= 0.0f) & (vw <= (float)(g.h - 1));
+    o.x = xn; o.y = yn; o.z = z; o.uw = uw; o.vw = vw; o.ok = ok;
     // tap offset y0 * pitch + x0, formed in float32 (exact: < 2^24) to save a conversion and an integer multiply
     o.off = ok ? (unsigned)fmaf(floorf(vw), (float)g.pitch, floorf(uw)) : 0u;
 }
@@ -319,9 +322,14 @@ __device__ __forceinline__ void dvo_geo(const DvoLevelGeom& g, const DvoLevelCam
 __device__ __forceinline__ void dvo_load_taps(const DvoLevelGeom& g, const uint32_t* __restrict__ cur,
                                               const PixelGeo& q, PixelTaps& t)
 {
-    const uint32_t* row0 = cur + q.off;
-    t.t0 = *reinterpret_cast<const u32x2_a4*>(row0);
-    t.t1 = *reinterpret_cast<const u32x2_a4*>(row0 + g.pitch);
+    // 32-bit byte offset from two wave-uniform row bases: the loads take the scalar base + vector offset form, no
+    // 64-bit address arithmetic per lane ((h+1)*pitch < 2^24 is checked at dvo_create, so the offset fits)
+    unsigned boff = q.off << 2;
+    asm("" : "+v"(boff));                 // keep the offset 32-bit up to the load (else the zero-extension is hoisted)
+    const char* base0 = reinterpret_cast<const char*>(cur);
+    const char* base1 = reinterpret_cast<const char*>(cur + g.pitch);
+    t.t0 = *reinterpret_cast<const u32x2_a4*>(base0 + boff);
+    t.t1 = *reinterpret_cast<const u32x2_a4*>(base1 + boff);
 }
 
 // Variant V3 (the reference's numba.cuda kernel, cuda/residuals_kernel.py:46-109): phase A with the arithmetic types
@@ -395,8 +403,10 @@ __device__ __forceinline__ void dvo_finish(const DvoLevelCam& cam, const PixelGe
         unpack_tap(t.own, Ip, gxw, gyw);                                        // :69-75 (Sobel of I1 at the pixel)
     }
     // --- J_w at the UN-warped point (utils/jacobian.py:39-42, quirk Q2) ------------------------------
-    const float iz = fast_rcp(q.z);
-    const float a = q.x * iz, b = q.y * iz;
+    // x/z and y/z are the normalised coordinates the point was built from (x = xn * z), and 1/z is v_rcp_f32 (1 ulp):
+    // both within 2e-7 relative of the reference's float32 quotients, far inside the 1e-5 bound on the increments.
+    const float iz = __builtin_amdgcn_rcpf(q.z);
+    const float a = q.x, b = q.y;
     const float fxg = cam.fx * gxw, fyg = cam.fy * gyw;
     // J = gx * Jw[0,:] + gy * Jw[1,:]   (_fill_jacobian, cpu_robust...:79-90)
     const float ab = a * b;
@@ -476,7 +486,7 @@ __device__ __forceinline__ void block_reduce_terms(const float* acc, double* out
 #endif
 // TAG only names the instantiation so that rocprofv3 --stats lists these dispatches on their own line; codegen is
 // identical.  0: coarser levels, 1: level 0, 2: level 0 while the ctx is in profiling mode (bench.py's roofline leg).
-template <int VARIANT, int WMODE, bool SCALE_PASS, int TAG>
+template <int VARIANT, int WMODE, bool SCALE_PASS, int TAG, bool SKEW>
 __global__ __launch_bounds__(DVO_BLOCK, (VARIANT == 2) ? 2 : DVO_REDUCE_WAVES_PER_SIMD) void k_reduce(const DvoReduceParams p)
 {
     constexpr int NACC = SCALE_PASS ? 1 : DVO_NACC;
@@ -607,7 +617,7 @@ __global__ __launch_bounds__(DVO_BLOCK, (VARIANT == 2) ? 2 : DVO_REDUCE_WAVES_PE
 #pragma unroll
         for (int j = 0; j < DVO_PX_PER_THREAD; ++j) {
             if constexpr (VARIANT == 2) dvo_geo_v3(p.g, p.cam, p.depth_scale, T, gray_prev, px[j], py[j], dd[j], geo[j], jv3[j]);
-            else dvo_geo(p.g, p.cam, p.depth_scale, T, px[j], py[j], dd[j], geo[j]);
+            else dvo_geo<SKEW>(p.g, p.cam, p.depth_scale, T, px[j], py[j], dd[j], geo[j]);
             dvo_load_taps(p.g, packed_cur, geo[j], taps[j]);
             if (VARIANT == 1) taps[j].own = geo[j].ok ? packed_prev[(unsigned)(py[j] * p.g.pitch + px[j])] : 0u;
         }
@@ -669,35 +679,39 @@ __global__ __launch_bounds__(DVO_BLOCK, (VARIANT == 2) ? 2 : DVO_REDUCE_WAVES_PE
     }
 }
 
-template <int VARIANT, int TAG>
+template <int VARIANT, int TAG, bool SKEW>
 static hipError_t launch_reduce_v(const DvoReduceParams& p, int weight_mode, int scale_pass, hipStream_t s)
 {
     dim3 grid((unsigned)(p.n_pairs * p.blocks_per_pair)), block(DVO_BLOCK);
     if (scale_pass) {
-        hipLaunchKernelGGL((k_reduce<VARIANT, 1, true, TAG>), grid, block, 0, s, p);
+        hipLaunchKernelGGL((k_reduce<VARIANT, 1, true, TAG, SKEW>), grid, block, 0, s, p);
     } else if (weight_mode == 0) {
-        hipLaunchKernelGGL((k_reduce<VARIANT, 0, false, TAG>), grid, block, 0, s, p);
+        hipLaunchKernelGGL((k_reduce<VARIANT, 0, false, TAG, SKEW>), grid, block, 0, s, p);
     } else if (weight_mode == 1) {
-        hipLaunchKernelGGL((k_reduce<VARIANT, 1, false, TAG>), grid, block, 0, s, p);
+        hipLaunchKernelGGL((k_reduce<VARIANT, 1, false, TAG, SKEW>), grid, block, 0, s, p);
     } else {
-        hipLaunchKernelGGL((k_reduce<VARIANT, 2, false, TAG>), grid, block, 0, s, p);
+        hipLaunchKernelGGL((k_reduce<VARIANT, 2, false, TAG, SKEW>), grid, block, 0, s, p);
     }
     return hipGetLastError();
 }
 
 hipError_t dvo_launch_reduce(const DvoReduceParams& p, int variant, int weight_mode, int scale_pass, hipStream_t s)
 {
-    if (variant == 2) return launch_reduce_v<2, 0>(p, weight_mode, scale_pass, s);      // V3: no per-level kernel tags
+    if (variant == 2) return launch_reduce_v<2, 0, false>(p, weight_mode, scale_pass, s);      // V3: no per-level kernel tags
+    if (!p.cam.skew0) {                         // cameras with a skew term: general expressions, no per-level tags
+        if (variant == 0) return launch_reduce_v<0, 0, true>(p, weight_mode, scale_pass, s);
+        return launch_reduce_v<1, 0, true>(p, weight_mode, scale_pass, s);
+    }
     if (p.finest == 2) {
-        if (variant == 0) return launch_reduce_v<0, 2>(p, weight_mode, scale_pass, s);
-        return launch_reduce_v<1, 2>(p, weight_mode, scale_pass, s);
+        if (variant == 0) return launch_reduce_v<0, 2, false>(p, weight_mode, scale_pass, s);
+        return launch_reduce_v<1, 2, false>(p, weight_mode, scale_pass, s);
     }
     if (p.finest == 1) {
-        if (variant == 0) return launch_reduce_v<0, 1>(p, weight_mode, scale_pass, s);
-        return launch_reduce_v<1, 1>(p, weight_mode, scale_pass, s);
+        if (variant == 0) return launch_reduce_v<0, 1, false>(p, weight_mode, scale_pass, s);
+        return launch_reduce_v<1, 1, false>(p, weight_mode, scale_pass, s);
     }
-    if (variant == 0) return launch_reduce_v<0, 0>(p, weight_mode, scale_pass, s);
-    return launch_reduce_v<1, 0>(p, weight_mode, scale_pass, s);
+    if (variant == 0) return launch_reduce_v<0, 0, false>(p, weight_mode, scale_pass, s);
+    return launch_reduce_v<1, 0, false>(p, weight_mode, scale_pass, s);
 }
 
 // ================================================================================================
@@ -765,7 +779,8 @@ __global__ __launch_bounds__(DVO_BLOCK) void k_dense(const DvoDenseParams p)
         for (int i = 0; i < 12; ++i) T[i] = p.T[i];
         float jpre[6];
         if constexpr (VARIANT == 2) dvo_geo_v3(p.g, p.cam, p.depth_scale, T, gray_prev, ux, vy, d, q, jpre);
-        else dvo_geo(p.g, p.cam, p.depth_scale, T, ux, vy, d, q);
+        else if (p.cam.skew0) dvo_geo<false>(p.g, p.cam, p.depth_scale, T, ux, vy, d, q);
+        else dvo_geo<true>(p.g, p.cam, p.depth_scale, T, ux, vy, d, q);
         if (q.ok) {
             PixelTaps t;
             dvo_load_taps(p.g, packed_cur, q, t);
