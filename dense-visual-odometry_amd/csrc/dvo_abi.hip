@@ -133,6 +133,10 @@ void level_geometry(int w, int h, int levels, DvoLevelGeom* g, size_t* total)
         g[l].h = lh;
         g[l].npix = lw * lh;
         g[l].pitch = (int)align_up((size_t)lw + 2, 16);
+        g[l].wmax_f = (float)(lw - 1);
+        g[l].hmax_f = (float)(lh - 1);
+        g[l].pitch_f = (float)g[l].pitch;
+        g[l].pad_ = 0;
         g[l].off_gray = off;
         off = align_up(off + (size_t)lw * lh + 64, 256);
         g[l].off_depth = off;

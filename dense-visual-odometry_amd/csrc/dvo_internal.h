@@ -17,6 +17,9 @@
 // One pyramid level of a frame slot: byte offsets inside the slot, image size, packed-plane pitch (pixels).
 struct DvoLevelGeom {
     int w, h, pitch, npix;
+    float wmax_f, hmax_f, pitch_f;      // (float)(w-1), (float)(h-1), (float)pitch: kernel arguments live in SGPRs and gfx950
+                                        // has no scalar int->float conversion
+    int pad_;
     size_t off_gray, off_depth, off_packed;
 };
 

@@ -233,6 +233,7 @@ struct PixelOut {
 struct PixelGeo {
     float x, y, z;       // back-projected point (un-warped) as (x/z, y/z, z): x/z, y/z are the normalised pixel coordinates
     float uw, vw;        // warped pixel coordinates
+    float ax, ay;        // their fractional parts uw - floor(uw), vw - floor(vw) (exact)
     unsigned off;        // offset of tap (y0, x0) in the packed plane (0 when !ok, so the load is harmless)
     bool ok;             // depth != 0 && warped point inside the closed image rectangle
 };
@@ -288,6 +289,7 @@ __device__ __forceinline__ void dvo_geo(const DvoLevelGeom& g, const DvoLevelCam
     o.off = 0u;
     o.x = o.y = o.z = 0.0f;             // (leaving these unset makes LLVM copy all 30 accumulators at every join)
     o.uw = o.vw = __builtin_nanf("");
+    o.ax = o.ay = 0.0f;
     if (d == 0u) return;                                      // mask = depth != 0 (camera_model.py:195)
     // --- deproject (camera_model.py:195-221) -------------------------------------------------------
     const float z = dvo_depth_to_z(d, depth_scale, cam);
@@ -313,10 +315,15 @@ __device__ __forceinline__ void dvo_geo(const DvoLevelGeom& g, const DvoLevelCam
     const float uw = dvo_div_with_rcp(un, zp, rz);
     const float vw = dvo_div_with_rcp(vn, zp, rz);
     // closed-boundary rule: valid <=> 0 <= x <= W-1 and 0 <= y <= H-1 ; NaN compares false
-    const bool ok = (uw >= 0.0f) & (uw <= (float)(g.w - 1)) & (vw >= 0.0f) & (vw <= (float)(g.h - 1));
-    o.x = xn; o.y = yn; o.z = z; o.uw = uw; o.vw = vw; o.ok = ok;
+    // Non-negative floats order like their bit patterns and every negative float or NaN has a larger pattern than any
+    // bound, so one unsigned compare per coordinate decides 0 <= c <= max.  (-0.0 would be rejected where the float
+    // compare accepts it, but the division above cannot return -0.0 for a non-zero divisor.)
+    const bool ok = (int)(__float_as_uint(uw) <= __float_as_uint(g.wmax_f)) & (int)(__float_as_uint(vw) <= __float_as_uint(g.hmax_f));
+    // v_fract_f32 = c - floor(c), exact; floor(c) = c - fract(c), exact as well
+    const float ax = __builtin_amdgcn_fractf(uw), ay = __builtin_amdgcn_fractf(vw);
+    o.x = xn; o.y = yn; o.z = z; o.uw = uw; o.vw = vw; o.ax = ax; o.ay = ay; o.ok = ok;
     // tap offset y0 * pitch + x0, formed in float32 (exact: < 2^24) to save a conversion and an integer multiply
-    o.off = ok ? (unsigned)fmaf(floorf(vw), (float)g.pitch, floorf(uw)) : 0u;
+    o.off = ok ? (unsigned)fmaf(vw - ay, g.pitch_f, uw - ax) : 0u;
 }
 
 __device__ __forceinline__ void dvo_load_taps(const DvoLevelGeom& g, const uint32_t* __restrict__ cur,
@@ -345,6 +352,7 @@ __device__ __forceinline__ void dvo_geo_v3(const DvoLevelGeom& g, const DvoLevel
     o.off = 0u;
     o.x = o.y = o.z = 0.0f;
     o.uw = o.vw = __builtin_nanf("");
+    o.ax = o.ay = 0.0f;
 #pragma unroll
     for (int k = 0; k < 6; ++k) J[k] = 0.0f;
     if (d == 0u) return;                                                          // :60-65
@@ -370,7 +378,7 @@ __device__ __forceinline__ void dvo_geo_v3(const DvoLevelGeom& g, const DvoLevel
     const float wy = (float)(fy * y1 / z1 + cy);
     const float x0 = floorf(wx), y0 = floorf(wy);
     const bool ok = (x0 >= 0.0f) && (y0 >= 0.0f) && (x0 + 1.0f < (float)g.w) && (y0 + 1.0f < (float)g.h);
-    o.uw = wx; o.vw = wy; o.ok = ok;
+    o.uw = wx; o.vw = wy; o.ax = wx - x0; o.ay = wy - y0; o.ok = ok;
     o.off = ok ? (unsigned)fmaf(y0, (float)g.pitch, x0) : 0u;
 }
 
@@ -382,8 +390,7 @@ __device__ __forceinline__ void dvo_finish(const DvoLevelCam& cam, const PixelGe
                                            unsigned i1, PixelOut& o)
 {
     // --- bilinear weights (cpu_robust...:202-254) ------------------------------------------------------
-    const float x0f = floorf(q.uw), y0f = floorf(q.vw);
-    const float ax = q.uw - x0f, ay = q.vw - y0f;          // exact
+    const float ax = q.ax, ay = q.ay;                      // uw - floor(uw), vw - floor(vw): exact
     const float bx = 1.0f - ax, by = 1.0f - ay;            // == (x0+1) - x up to one rounding when x < 1
     const float w00 = bx * by, w01 = bx * ay, w10 = ax * by, w11 = ax * ay;
     float I00, I10, I01, I11, gx00, gx10, gx01, gx11, gy00, gy10, gy01, gy11;
@@ -481,6 +488,9 @@ __device__ __forceinline__ void block_reduce_terms(const float* acc, double* out
 #ifndef DVO_COMPACT
 #define DVO_COMPACT 1
 #endif
+#ifndef DVO_VCONST
+#define DVO_VCONST 0
+#endif
 #ifndef DVO_REDUCE_WAVES_PER_SIMD
 #define DVO_REDUCE_WAVES_PER_SIMD 4
 #endif
@@ -512,6 +522,19 @@ __global__ __launch_bounds__(DVO_BLOCK, (VARIANT == 2) ? 2 : DVO_REDUCE_WAVES_PE
     float T[12];
 #pragma unroll
     for (int i = 0; i < 12; ++i) T[i] = p.T[pair * 12 + i];
+    DvoLevelCam cam = p.cam;
+#if DVO_VCONST
+    // On gfx950 a VALU instruction with an SGPR source issues at the slow rate (4.4-5.0 vs 3.1-3.4 cycles per wave64
+    // instruction, tools/ubench/valu_asm.hip), and every multiply of the geometry has a constant factor: keep the
+    // pose and the intrinsics in VGPRs.
+    if constexpr (VARIANT != 2) {
+#pragma unroll
+        for (int i = 0; i < 12; ++i) asm volatile("" : "+v"(T[i]));
+        asm volatile("" : "+v"(cam.fx), "+v"(cam.fy), "+v"(cam.cx), "+v"(cam.cy));
+        asm volatile("" : "+v"(cam.ia), "+v"(cam.ic), "+v"(cam.id), "+v"(cam.ie));
+        asm volatile("" : "+v"(cam.ds_hi), "+v"(cam.ds_lo));
+    }
+#endif
     float wpar = 0.0f;
     if (WMODE != 0) wpar = (float)p.wparam[pair];
 
@@ -616,8 +639,8 @@ __global__ __launch_bounds__(DVO_BLOCK, (VARIANT == 2) ? 2 : DVO_REDUCE_WAVES_PE
         float jv3[(VARIANT == 2) ? DVO_PX_PER_THREAD : 1][6];
 #pragma unroll
         for (int j = 0; j < DVO_PX_PER_THREAD; ++j) {
-            if constexpr (VARIANT == 2) dvo_geo_v3(p.g, p.cam, p.depth_scale, T, gray_prev, px[j], py[j], dd[j], geo[j], jv3[j]);
-            else dvo_geo<SKEW>(p.g, p.cam, p.depth_scale, T, px[j], py[j], dd[j], geo[j]);
+            if constexpr (VARIANT == 2) dvo_geo_v3(p.g, cam, p.depth_scale, T, gray_prev, px[j], py[j], dd[j], geo[j], jv3[j]);
+            else dvo_geo<SKEW>(p.g, cam, p.depth_scale, T, px[j], py[j], dd[j], geo[j]);
             dvo_load_taps(p.g, packed_cur, geo[j], taps[j]);
             if (VARIANT == 1) taps[j].own = geo[j].ok ? packed_prev[(unsigned)(py[j] * p.g.pitch + px[j])] : 0u;
         }
@@ -625,7 +648,7 @@ __global__ __launch_bounds__(DVO_BLOCK, (VARIANT == 2) ? 2 : DVO_REDUCE_WAVES_PE
         for (int j = 0; j < DVO_PX_PER_THREAD; ++j) {
             if (geo[j].ok) {                                  // depth != 0 (camera_model.py:195) and in bounds
                 PixelOut o;
-                dvo_finish<VARIANT, !SCALE_PASS>(p.cam, geo[j], taps[j], ii[j], o);
+                dvo_finish<VARIANT, !SCALE_PASS>(cam, geo[j], taps[j], ii[j], o);
                 if constexpr (VARIANT == 2) {
 #pragma unroll
                     for (int k = 0; k < 6; ++k) o.J[k] = jv3[j][k];
@@ -770,6 +793,7 @@ __global__ __launch_bounds__(DVO_BLOCK) void k_dense(const DvoDenseParams p)
     q.ok = false;
     q.x = q.y = q.z = 0.0f;
     q.uw = q.vw = __builtin_nanf("");
+    q.ax = q.ay = 0.0f;
     o.r = 0.0f;
 #pragma unroll
     for (int k = 0; k < 6; ++k) o.J[k] = 0.0f;

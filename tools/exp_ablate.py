@@ -4,6 +4,7 @@ import sys
 from pathlib import Path
 ROOT = Path(__file__).resolve().parents[1]
 sys.path.insert(0, str(ROOT / "dense-visual-odometry_amd"))
+import os
 import numpy as np
 from dvo_amd import synthetic
 from dvo_amd.batch import BatchAligner
@@ -19,7 +20,7 @@ for lvl in range(4):
     for _ in range(2):
         al.ctx.normal_equations(lvl, prev, prev + 1, T)
     al.ctx.profile_enable(True); al.ctx.profile_read(True)
-    for _ in range(10):
+    for _ in range(int(os.environ.get('DVO_EXP_LAUNCHES', '10'))):
         al.ctx.normal_equations(lvl, prev, prev + 1, T)
     n, ms = al.ctx.profile_read(True)
     al.ctx.profile_enable(False)

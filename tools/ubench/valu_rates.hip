@@ -24,6 +24,13 @@ __global__ __launch_bounds__(256) void k(float* out, float a, float b, int n)
         if (OP == 8) { APPLY([&](float x) { return __int_as_float((__float_as_int(x) >> 3) & 0x3fffffff); }) }   // shift + and
         if (OP == 9) { APPLY([&](float x) { return (float)((double)x * 1.0000001); }) }      // cvt f64, mul f64, cvt f32
         if (OP == 10) { APPLY([&](float x) { return __int_as_float(__float_as_int(x) * 3 + 1); }) }   // v_mul_lo_u32 / mad
+        if (OP == 11) { APPLY([&](float x) { return (float)__float_as_int(x); }) }                     // v_cvt_f32_i32
+        if (OP == 12) { APPLY([&](float x) { return (float)(__float_as_uint(x) & 0xffu); }) }
+        if (OP == 13) { APPLY([&](float x) { return (float)__builtin_bit_cast(_Float16, (unsigned short)__float_as_uint(x)); }) }          // v_cvt_f32_f16
+        if (OP == 14) { APPLY([&](float x) { return (float)__builtin_bit_cast(_Float16, (unsigned short)(__float_as_uint(x) >> 16)); }) }  // ... src0_sel:WORD_1
+        if (OP == 15) { APPLY([&](float x) { return __int_as_float((__float_as_int(x) << 12) >> 20); }) }                                   // v_bfe_i32
+        if (OP == 16) { APPLY([&](float x) { return (float)((__float_as_uint(x) >> 16) & 0xffu); }) }
+        if (OP == 17) { APPLY([&](float x) { return __builtin_floorf(x); }) }
     }
     out[blockIdx.x * 256 + threadIdx.x] = r0 + r1 + r2 + r3 + r4 + r5 + r6 + r7;
 }
@@ -31,7 +38,8 @@ __global__ __launch_bounds__(256) void k(float* out, float a, float b, int n)
 int main()
 {
     const char* names[] = {"v_fma_f32", "v_mul_f32", "v_add_f32", "v_rcp_f32", "cvt f32->i32->f32 (2 instr)", "IEEE div f32 (~10 instr)",
-                           "v_cmp + v_cndmask (2)", "v_floor + v_add (2)", "v_ashr + v_and (2)", "cvt_f64 + mul_f64 + cvt_f32 (3)", "int mul/mad 32-bit"};
+                           "v_cmp + v_cndmask (2)", "v_floor + v_add (2)", "v_ashr + v_and (2)", "cvt_f64 + mul_f64 + cvt_f32 (3)", "int mul/mad 32-bit",
+                           "v_cvt_f32_i32", "v_cvt_f32_ubyte0", "v_cvt_f32_f16", "v_cvt_f32_f16 sdwa WORD_1", "v_bfe_i32", "v_cvt_f32_ubyte2", "v_floor_f32"};
     hipDeviceProp_t prop;
     CHK(hipGetDeviceProperties(&prop, 0));
     const int cus = prop.multiProcessorCount;
@@ -41,12 +49,12 @@ int main()
     hipEvent_t e0, e1;
     CHK(hipEventCreate(&e0)); CHK(hipEventCreate(&e1));
     printf("%d CUs, clock %.0f MHz (reported), %d blocks\n", cus, prop.clockRate / 1e3, blocks);
-    for (int op = 0; op <= 10; ++op) {
+    for (int op = 0; op <= 17; ++op) {
         for (int rep = 0; rep < 2; ++rep) {
             CHK(hipEventRecord(e0));
             switch (op) {
 #define L(N) case N: hipLaunchKernelGGL(k<N>, dim3(blocks), dim3(256), 0, 0, d, 1.0001f, 0.5f, ITERS); break;
-                L(0) L(1) L(2) L(3) L(4) L(5) L(6) L(7) L(8) L(9) L(10)
+                L(0) L(1) L(2) L(3) L(4) L(5) L(6) L(7) L(8) L(9) L(10) L(11) L(12) L(13) L(14) L(15) L(16) L(17)
             }
             CHK(hipEventRecord(e1));
             CHK(hipEventSynchronize(e1));
