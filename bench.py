@@ -192,7 +192,8 @@ def main():
     if rank == 0:
         P0 = W * H
         alg_bytes = (2.0 * P0 + 10.0 * valid_l0) * npr                # SURVEY 8d, per level-0 launch
-        layout_bytes = (2.0 * P0 + 5.0 * valid_l0) * npr              # this build's packed layout
+        layout_bytes = (4.0 * P0 + 8.0 * valid_l0) * npr              # this build's layout: 8-byte valid-point records of
+                                                                      # frame 1 + the 4-byte packed texels of frame 2
         avg_ms = ms[0] / max(launches[0], 1)
         achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
         per_level = {str(l): {"launches": int(launches[l]), "avg_us": (1e3 * ms[l] / launches[l]) if launches[l] else None}

@@ -18,6 +18,7 @@ thread_local char g_create_error[512] = "";
 struct SlotInfo {
     int w = 0, h = 0, levels = 0;
     bool ready = false;
+    bool lists = false;     // valid-point lists built (needs the camera's depth_scale at upload time)
 };
 
 struct HostStage {          // pinned staging for the small per-call arrays
@@ -63,6 +64,9 @@ struct dvo_ctx {
     int* d_active = nullptr;
     int* d_frame_slots = nullptr;
     int* h_frame_slots = nullptr;
+    int* d_list_count = nullptr;         // [n_slots][DVO_LIST_LEVELS] records in each slot's valid-point lists
+    int* d_seg_counts = nullptr;         // list-builder scratch [n_slots][segments of all levels]
+    int segs_per_frame = 0;
     double* d_partials = nullptr;
     size_t partials_doubles = 0;
     double* d_out = nullptr;
@@ -136,13 +140,15 @@ void level_geometry(int w, int h, int levels, DvoLevelGeom* g, size_t* total)
         g[l].wmax_f = (float)(lw - 1);
         g[l].hmax_f = (float)(lh - 1);
         g[l].pitch_f = (float)g[l].pitch;
-        g[l].pad_ = 0;
+        g[l].nseg = (lw * lh + DVO_LIST_SEG - 1) / DVO_LIST_SEG;
         g[l].off_gray = off;
         off = align_up(off + (size_t)lw * lh + 64, 256);
         g[l].off_depth = off;
         off = align_up(off + (size_t)lw * lh * 2 + 64, 256);
         g[l].off_packed = off;
         off = align_up(off + (size_t)(lh + 1) * g[l].pitch * 4 + 64, 256);
+        g[l].off_list = off;
+        off = align_up(off + (size_t)lw * lh * sizeof(DvoPointRec) + DVO_LIST_SLACK + 64, 256);
         lw = (lw + 1) / 2;
         lh = (lh + 1) / 2;
     }
@@ -194,6 +200,8 @@ int check_pairs(dvo_ctx* ctx, int n_pairs, const int* prev_slot, const int* cur_
     if (!prev_slot || !cur_slot) return fail(ctx, DVO_ERR_INVALID_ARG, "null slot arrays");
     for (int i = 0; i < n_pairs; ++i) {
         int rc = check_slot(ctx, prev_slot[i], "prev");
+        if (rc == DVO_OK && !ctx->slots[prev_slot[i]].lists)
+            rc = fail(ctx, DVO_ERR_BAD_STATE, "slot %d was uploaded before dvo_set_camera (or under another depth_scale): upload it again", prev_slot[i]);
         if (rc) return rc;
         rc = check_slot(ctx, cur_slot[i], "cur");
         if (rc) return rc;
@@ -268,6 +276,8 @@ int fill_reduce_params(dvo_ctx* ctx, int level, int n_pairs, int w, int h, DvoRe
     p->active = nullptr;
     p->finest = (level == 0) ? (ctx->profiling ? 2 : 1) : 0;
     p->partials = ctx->d_partials;
+    p->list_count = ctx->d_list_count;
+    p->level = level;
     {
         const char* e = getenv("DVO_XCD_REMAP");
         p->xcd_remap = (e && e[0] == '1') ? 1 : 0;   // measured slower on MI355X, off by default
@@ -305,6 +315,9 @@ int build_pyramid_on_device(dvo_ctx* ctx, int slot, int w, int h, int levels)
     p.src_depth = nullptr;
     p.n_frames = 1;
     p.levels = levels;
+    p.depth_scale = ctx->depth_scale;
+    p.list_count = ctx->d_list_count;
+    p.seg_counts = ctx->d_seg_counts;
     level_geometry(w, h, levels, p.g, nullptr);
     ctx->h_frame_slots[0] = slot;
     HIP_TRY(ctx, hipMemcpyAsync(ctx->d_frame_slots, ctx->h_frame_slots, sizeof(int), hipMemcpyHostToDevice, ctx->stream));
@@ -325,6 +338,7 @@ int prepare_slot(dvo_ctx* ctx, int slot, int w, int h, int levels)
         HIP_TRY(ctx, hipMemsetAsync(ctx->d_slots + (size_t)slot * ctx->slot_stride, 0, ctx->slot_stride, ctx->stream));
     }
     s.w = w; s.h = h; s.levels = levels; s.ready = false;
+    s.lists = ctx->have_camera;      // the valid-point lists built at ingest hold z = depth * depth_scale
     return DVO_OK;
 }
 
@@ -342,8 +356,9 @@ int dvo_create(int device, int max_w, int max_h, int max_levels, int n_slots, in
     if (max_w <= 0 || max_h <= 0 || max_levels < 1 || max_levels > DVO_MAX_LEVELS || n_slots < 2 || max_pairs < 1)
         return fail(nullptr, DVO_ERR_INVALID_ARG, "dvo_create: bad sizes (max %dx%d, levels %d, slots %d, pairs %d)", max_w, max_h, max_levels, n_slots, max_pairs);
     // the kernels form tap offsets y * pitch + x in float32 and pack pixel coordinates in 16 bits
-    if ((double)(max_h + 1) * (double)align_up((size_t)max_w + 2, 16) >= 16777216.0 || max_w > 65535 || max_h > 65535)
-        return fail(nullptr, DVO_ERR_INVALID_ARG, "dvo_create: %dx%d exceeds the supported image size ((h+1)*pitch must stay below 2^24)", max_w, max_h);
+    // the kernels form tap offsets y * pitch + x in float32 and the valid-point records hold x and y in 12 bits each
+    if ((double)(max_h + 1) * (double)align_up((size_t)max_w + 2, 16) >= 16777216.0 || max_w > 4096 || max_h > 4096)
+        return fail(nullptr, DVO_ERR_INVALID_ARG, "dvo_create: %dx%d exceeds the supported image size (at most 4096x4096 and (h+1)*pitch below 2^24)", max_w, max_h);
     int ndev = 0;
     hipError_t e = hipGetDeviceCount(&ndev);
     if (e != hipSuccess || ndev <= 0) return fail(nullptr, DVO_ERR_NO_DEVICE, "dvo_create: no HIP device (%s); there is no CPU fallback", hipGetErrorString(e));
@@ -382,6 +397,10 @@ int dvo_create(int device, int max_w, int max_h, int max_levels, int n_slots, in
     CREATE_TRY(hipMalloc((void**)&ctx->d_active, np * sizeof(int)));
     CREATE_TRY(hipMalloc((void**)&ctx->d_frame_slots, (size_t)n_slots * sizeof(int)));
     CREATE_TRY(hipHostMalloc((void**)&ctx->h_frame_slots, (size_t)n_slots * sizeof(int)));
+    for (int l = 0; l < lv; ++l) ctx->segs_per_frame += g[l].nseg;
+    CREATE_TRY(hipMalloc((void**)&ctx->d_list_count, (size_t)n_slots * DVO_LIST_LEVELS * sizeof(int)));
+    CREATE_TRY(hipMemsetAsync(ctx->d_list_count, 0, (size_t)n_slots * DVO_LIST_LEVELS * sizeof(int), ctx->stream));
+    CREATE_TRY(hipMalloc((void**)&ctx->d_seg_counts, (size_t)n_slots * (size_t)ctx->segs_per_frame * sizeof(int)));
     ctx->partials_doubles = np * (size_t)blocks_for(max_w * max_h) * DVO_STRIDE;
     CREATE_TRY(hipMalloc((void**)&ctx->d_partials, ctx->partials_doubles * sizeof(double)));
     CREATE_TRY(hipMalloc((void**)&ctx->d_out, np * DVO_STRIDE * sizeof(double)));
@@ -428,7 +447,8 @@ void dvo_destroy(dvo_ctx* ctx)
     if (ctx->ev_staging) (void)hipEventDestroy(ctx->ev_staging);
     if (ctx->ev_order) (void)hipEventDestroy(ctx->ev_order);
     void* dev[] = {ctx->d_slots, ctx->d_prev, ctx->d_cur, ctx->d_T, ctx->d_Tinit, ctx->d_wparam, ctx->d_active, ctx->d_partials,
-                   ctx->d_out, ctx->d_state, ctx->d_xi, ctx->d_iters, ctx->d_err, ctx->d_stage_img, ctx->d_dense, ctx->d_trace, ctx->d_frame_slots, ctx->d_prior, ctx->d_batch_stage};
+                   ctx->d_out, ctx->d_state, ctx->d_xi, ctx->d_iters, ctx->d_err, ctx->d_stage_img, ctx->d_dense, ctx->d_trace, ctx->d_frame_slots, ctx->d_prior, ctx->d_batch_stage,
+                   ctx->d_list_count, ctx->d_seg_counts};
     for (void* p : dev) if (p) (void)hipFree(p);
     void* host[] = {ctx->hs.prev, ctx->hs.cur, ctx->hs.T, ctx->hs.wparam, ctx->hs.out, ctx->hs.xi, ctx->hs.iters, ctx->hs.err, ctx->h_frame_slots, ctx->h_prior};
     for (void* p : host) if (p) (void)hipHostFree(p);
@@ -458,6 +478,8 @@ int dvo_set_camera(dvo_ctx* ctx, float fx, float fy, float cx, float cy, float s
     if (!ctx) return DVO_ERR_INVALID_ARG;
     if (!(fx > 0.f) || !(fy > 0.f) || !(depth_scale >= 0.0) || !std::isfinite(cx) || !std::isfinite(cy) || !std::isfinite(skew))
         return fail(ctx, DVO_ERR_INVALID_ARG, "dvo_set_camera: need fx, fy > 0 and depth_scale >= 0");
+    if (!ctx->have_camera || depth_scale != ctx->depth_scale)
+        for (SlotInfo& si : ctx->slots) si.lists = false;      // their valid-point lists hold z for the old scale
     ctx->fx = fx; ctx->fy = fy; ctx->cx = cx; ctx->cy = cy; ctx->skew = skew; ctx->depth_scale = depth_scale;
     // float32 double-word form of depth_scale; usable in the kernels only if it reproduces the reference's
     // (float)((double)d * depth_scale) for every 16-bit depth value — checked here, exhaustively.
@@ -550,6 +572,9 @@ int dvo_upload_frames_device(dvo_ctx* ctx, int n_frames, const int* slots, const
     p.src_depth = static_cast<const uint16_t*>(d_depth);
     p.n_frames = n_frames;
     p.levels = levels;
+    p.depth_scale = ctx->depth_scale;
+    p.list_count = ctx->d_list_count;
+    p.seg_counts = ctx->d_seg_counts;
     level_geometry(w, h, levels, p.g, nullptr);
     memcpy(ctx->h_frame_slots, slots, (size_t)n_frames * sizeof(int));
     HIP_TRY(ctx, hipMemcpyAsync(ctx->d_frame_slots, ctx->h_frame_slots, (size_t)n_frames * sizeof(int), hipMemcpyHostToDevice, ctx->stream));

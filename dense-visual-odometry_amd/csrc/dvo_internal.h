@@ -19,9 +19,21 @@ struct DvoLevelGeom {
     int w, h, pitch, npix;
     float wmax_f, hmax_f, pitch_f;      // (float)(w-1), (float)(h-1), (float)pitch: kernel arguments live in SGPRs and gfx950
                                         // has no scalar int->float conversion
-    int pad_;
+    int nseg;                           // ceil(npix / 1024): 1024-pixel segments of the valid-point list builder
     size_t off_gray, off_depth, off_packed;
+    size_t off_list;                    // valid-point list: one 8-byte DvoPointRec per depth-valid pixel, raster order
 };
+
+// Valid-point list (built once per frame and level at ingest, read by every Gauss-Newton iteration): the pixels with
+// depth != 0 (camera_model.py:195) in raster order.  z = (float)((double)depth * depth_scale) (camera_model.py:200-201)
+// is iteration-invariant, so it is computed once here; pix = x | y << 12 | intensity << 24.
+struct DvoPointRec {
+    float z;
+    uint32_t pix;
+};
+#define DVO_LIST_SLACK 2048             // bytes readable past the last record (a partly filled wave reads whole segments)
+#define DVO_LIST_SEG 1024               // pixels per list-builder segment
+#define DVO_LIST_LEVELS 8                // == DVO_MAX_LEVELS
 
 // Level intrinsics K_L (RGBDCameraModel.at, camera_model.py:62-79) and the entries of inv(K_L)
 // (camera_model.py:219) spelled out as in oracle/dvo_oracle.py:inverse_intrinsics.
@@ -48,8 +60,10 @@ struct DvoReduceParams {
     int blocks_per_pair;
     int xcd_remap;              // 1: XCD-aware logical block order
     int finest;                 // level == 0 (kernel-name tag only)
-    int groups_per_block;       // each workgroup reduces groups_per_block * DVO_PX_PER_BLOCK pixels of one pair
+    int groups_per_block;       // each workgroup reduces groups_per_block * DVO_PX_PER_BLOCK list records of one pair
     int n_pairs;
+    const int* list_count;      // [n_slots][DVO_LIST_LEVELS] number of records in each slot's list
+    int level;
 };
 
 struct DvoDenseParams {
@@ -107,6 +121,9 @@ struct DvoBatchIngestParams {
     const uint16_t* src_depth;   // [n_frames][h][w] device
     int n_frames, levels;
     DvoLevelGeom g[8];
+    double depth_scale;          // for the valid-point lists
+    int* list_count;             // [n_slots][DVO_LIST_LEVELS]
+    int* seg_counts;             // scratch [n_frames][sum of g[l].nseg]: per-segment counts, then exclusive offsets
 };
 
 // launch wrappers implemented in dvo_kernels.hip -------------------------------------------------

@@ -206,6 +206,130 @@ __global__ __launch_bounds__(DVO_BLOCK) void k_batch_sobel_pack(const DvoBatchIn
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Valid-point lists.  Per frame and level: the pixels with depth != 0, in raster order, one DvoPointRec each.  Three
+// launches for the whole batch and all levels: per-segment counts, exclusive scan per (frame, level), ordered scatter.
+// A segment is DVO_LIST_SEG = 1024 consecutive pixels handled by one wave, lane L taking the 16 consecutive pixels
+// 16 L .. 16 L + 15 (two 16-byte depth loads, one 16-byte intensity load).  The scatter compacts the records of a
+// segment in LDS (lane-major order == raster order) and writes them out as whole cache lines.  Deterministic.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int list_level_of_segment(const DvoBatchIngestParams& p, int seg, int& seg_in_level)
+{
+    int l = 0;
+    while (l + 1 < p.levels && seg >= p.g[l].nseg) { seg -= p.g[l].nseg; ++l; }
+    seg_in_level = seg;
+    return l;
+}
+
+__device__ __forceinline__ int wave_sum_i(int v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+template <bool SCATTER>
+__global__ __launch_bounds__(DVO_BLOCK) void k_list_build(const DvoBatchIngestParams p, int segs_per_frame)
+{
+    __shared__ DvoPointRec stage[SCATTER ? DVO_BLOCK / 64 : 1][SCATTER ? DVO_LIST_SEG : 1];
+    const int f = blockIdx.z;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int seg = (int)blockIdx.x * (DVO_BLOCK / 64) + wave;
+    if (seg >= segs_per_frame) return;                                     // wave-uniform
+    int sl;
+    const int l = list_level_of_segment(p, seg, sl);
+    const DvoLevelGeom& g = p.g[l];
+    uint8_t* slot = p.slots + (size_t)p.slot_ids[f] * p.slot_stride;
+    const uint16_t* depth = reinterpret_cast<const uint16_t*>(slot + g.off_depth);
+    const int idx0 = sl * DVO_LIST_SEG + lane * 16;
+    unsigned dw[8];                                                        // 16 depths, two per word
+    if (idx0 + 16 <= g.npix) {
+        const uint4 a = *reinterpret_cast<const uint4*>(depth + idx0), b = *reinterpret_cast<const uint4*>(depth + idx0 + 8);
+        dw[0] = a.x; dw[1] = a.y; dw[2] = a.z; dw[3] = a.w; dw[4] = b.x; dw[5] = b.y; dw[6] = b.z; dw[7] = b.w;
+    } else {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int i0 = idx0 + 2 * k, i1 = i0 + 1;
+            dw[k] = ((i0 < g.npix) ? (unsigned)depth[i0] : 0u) | (((i1 < g.npix) ? (unsigned)depth[i1] : 0u) << 16);
+        }
+    }
+    int cnt = 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) cnt += ((dw[k] & 0xffffu) != 0u) + ((dw[k] >> 16) != 0u);
+    int* segc = p.seg_counts + (size_t)f * segs_per_frame + seg;
+    if (!SCATTER) {
+        const int tot = wave_sum_i(cnt);
+        if (lane == 0) *segc = tot;
+        return;
+    }
+    // exclusive prefix of the per-lane counts across the wave
+    int incl = cnt;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int v = __shfl_up(incl, off, 64);
+        if (lane >= off) incl += v;
+    }
+    const int total = __shfl(incl, 63, 64);
+    int pos = incl - cnt;
+    const uint8_t* gray = slot + g.off_gray;
+    unsigned gw[4];
+    if (idx0 + 16 <= g.npix) {
+        const uint4 a = *reinterpret_cast<const uint4*>(gray + idx0);
+        gw[0] = a.x; gw[1] = a.y; gw[2] = a.z; gw[3] = a.w;
+    } else {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            gw[k] = 0u;
+#pragma unroll
+            for (int b = 0; b < 4; ++b) if (idx0 + 4 * k + b < g.npix) gw[k] |= (unsigned)gray[idx0 + 4 * k + b] << (8 * b);
+        }
+    }
+    int y = idx0 / g.w, x = idx0 - y * g.w;
+    DvoPointRec* st = stage[wave];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        const unsigned d = (dw[k >> 1] >> ((k & 1) * 16)) & 0xffffu;
+        if (d != 0u) {
+            DvoPointRec rec;
+            rec.z = (float)((double)d * p.depth_scale);                    // camera_model.py:200-201
+            rec.pix = (unsigned)x | ((unsigned)y << 12) | (((gw[k >> 2] >> ((k & 3) * 8)) & 0xffu) << 24);
+            st[pos++] = rec;
+        }
+        if (++x == g.w) { x = 0; ++y; }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    DvoPointRec* list = reinterpret_cast<DvoPointRec*>(slot + g.off_list) + *segc;     // exclusive offset (k_list_scan)
+    for (int i = lane; i < total; i += 64) list[i] = st[i];
+}
+
+// exclusive scan of the per-segment counts of one (frame, level); total -> list_count[slot][level]
+__global__ __launch_bounds__(DVO_BLOCK) void k_list_scan(const DvoBatchIngestParams p, int segs_per_frame)
+{
+    __shared__ int part[DVO_BLOCK];
+    const int f = blockIdx.y, l = blockIdx.x;
+    int first = 0;
+    for (int k = 0; k < l; ++k) first += p.g[k].nseg;
+    int* c = p.seg_counts + (size_t)f * segs_per_frame + first;
+    const int n = p.g[l].nseg;
+    const int per = (n + DVO_BLOCK - 1) / DVO_BLOCK;
+    const int lo = min((int)threadIdx.x * per, n), hi = min(lo + per, n);
+    int sum = 0;
+    for (int i = lo; i < hi; ++i) sum += c[i];
+    part[threadIdx.x] = sum;
+    __syncthreads();
+    for (int off = 1; off < DVO_BLOCK; off <<= 1) {             // inclusive Hillis-Steele scan of the 256 partial sums
+        const int v = (threadIdx.x >= (unsigned)off) ? part[threadIdx.x - off] : 0;
+        __syncthreads();
+        part[threadIdx.x] += v;
+        __syncthreads();
+    }
+    int run = part[threadIdx.x] - sum;
+    for (int i = lo; i < hi; ++i) { const int v = c[i]; c[i] = run; run += v; }
+    if (threadIdx.x == DVO_BLOCK - 1) p.list_count[p.slot_ids[f] * DVO_LIST_LEVELS + l] = part[DVO_BLOCK - 1];
+}
+
 hipError_t dvo_launch_batch_ingest(const DvoBatchIngestParams& p, hipStream_t s)
 {
     const unsigned nf = (unsigned)p.n_frames;
@@ -218,6 +342,12 @@ hipError_t dvo_launch_batch_ingest(const DvoBatchIngestParams& p, hipStream_t s)
         if (l > 0) hipLaunchKernelGGL(k_batch_median_down, grid, dim3(DVO_BLOCK), 0, s, p, l);
         hipLaunchKernelGGL(k_batch_sobel_pack, grid, dim3(DVO_BLOCK), 0, s, p, l);
     }
+    int segs = 0;
+    for (int l = 0; l < p.levels; ++l) segs += p.g[l].nseg;
+    const unsigned lb = (unsigned)((segs + DVO_BLOCK / 64 - 1) / (DVO_BLOCK / 64));
+    hipLaunchKernelGGL(k_list_build<false>, dim3(lb, 1, nf), dim3(DVO_BLOCK), 0, s, p, segs);
+    hipLaunchKernelGGL(k_list_scan, dim3((unsigned)p.levels, nf), dim3(DVO_BLOCK), 0, s, p, segs);
+    hipLaunchKernelGGL(k_list_build<true>, dim3(lb, 1, nf), dim3(DVO_BLOCK), 0, s, p, segs);
     return hipGetLastError();
 }
 
@@ -282,18 +412,12 @@ __device__ __forceinline__ float dvo_div_with_rcp(float a, float b, float rb)
 // SKEW = false: the camera matrix has no skew term (K[0][1] == 0), so the zero products of the reference's matrix
 // expressions are skipped: x + (+-0) == x, exact.
 template <bool SKEW>
-__device__ __forceinline__ void dvo_geo(const DvoLevelGeom& g, const DvoLevelCam& cam, double depth_scale,
-                                        const float* __restrict__ T, int ux, int vy, unsigned d, PixelGeo& o)
+__device__ __forceinline__ void dvo_geo(const DvoLevelGeom& g, const DvoLevelCam& cam, const float* __restrict__ T,
+                                        float u, float v, float z, bool live, PixelGeo& o)
 {
-    o.ok = false;
-    o.off = 0u;
-    o.x = o.y = o.z = 0.0f;             // (leaving these unset makes LLVM copy all 30 accumulators at every join)
-    o.uw = o.vw = __builtin_nanf("");
-    o.ax = o.ay = 0.0f;
-    if (d == 0u) return;                                      // mask = depth != 0 (camera_model.py:195)
+    // `live` = the lane holds a depth-valid pixel (mask = depth != 0, camera_model.py:195); dead lanes compute on
+    // whatever they hold and are masked by `ok`.  z = (float)((double)depth * depth_scale) comes from the caller.
     // --- deproject (camera_model.py:195-221) -------------------------------------------------------
-    const float z = dvo_depth_to_z(d, depth_scale, cam);
-    const float u = (float)ux, v = (float)vy;
     const float xn = SKEW ? (((cam.ia * u) + (cam.ib * v)) + cam.ic) : ((cam.ia * u) + cam.ic);
     const float yn = (cam.id * v) + cam.ie;
     const float x = xn * z;
@@ -318,7 +442,7 @@ __device__ __forceinline__ void dvo_geo(const DvoLevelGeom& g, const DvoLevelCam
     // Non-negative floats order like their bit patterns and every negative float or NaN has a larger pattern than any
     // bound, so one unsigned compare per coordinate decides 0 <= c <= max.  (-0.0 would be rejected where the float
     // compare accepts it, but the division above cannot return -0.0 for a non-zero divisor.)
-    const bool ok = (int)(__float_as_uint(uw) <= __float_as_uint(g.wmax_f)) & (int)(__float_as_uint(vw) <= __float_as_uint(g.hmax_f));
+    const bool ok = (int)live & (int)(__float_as_uint(uw) <= __float_as_uint(g.wmax_f)) & (int)(__float_as_uint(vw) <= __float_as_uint(g.hmax_f));
     // v_fract_f32 = c - floor(c), exact; floor(c) = c - fract(c), exact as well
     const float ax = __builtin_amdgcn_fractf(uw), ay = __builtin_amdgcn_fractf(vw);
     o.x = xn; o.y = yn; o.z = z; o.uw = uw; o.vw = vw; o.ax = ax; o.ay = ay; o.ok = ok;
@@ -485,9 +609,6 @@ __device__ __forceinline__ void block_reduce_terms(const float* acc, double* out
     if (t >= 30 && t < DVO_STRIDE) out[t] = 0.0;
 }
 
-#ifndef DVO_COMPACT
-#define DVO_COMPACT 1
-#endif
 #ifndef DVO_VCONST
 #define DVO_VCONST 0
 #endif
@@ -542,96 +663,37 @@ __global__ __launch_bounds__(DVO_BLOCK, (VARIANT == 2) ? 2 : DVO_REDUCE_WAVES_PE
 #pragma unroll
     for (int i = 0; i < NACC; ++i) acc[i] = 0.0f;
 
-    // Pixel -> lane map: a wave owns 256 consecutive pixels per group and lane L takes pixels L, L+64, L+128,
-    // L+192 of it, so every load instruction of the wave (depth, intensity and the two 8-byte tap rows of the
-    // packed plane) covers 64 neighbouring pixels: whole 128-byte lines, no stride.
+    // Work items are the records of the previous frame's valid-point list (depth != 0, raster order, built once at
+    // ingest): no validity test, no pixel-index arithmetic and no empty lanes inside the Gauss-Newton loop.  A wave
+    // owns 256 consecutive records per group and lane L takes records L, L+64, L+128, L+192 of them, so every load
+    // instruction of the wave (the 8-byte records and, because neighbouring records are neighbouring pixels, the two
+    // 8-byte tap rows of the packed plane) covers whole cache lines.
     const int lane_ = threadIdx.x & 63, wave_ = threadIdx.x >> 6;
-    // depth / intensity of the next group are requested one group ahead, so their latency is covered by the
-    // arithmetic of the current group and only the dependent tap gathers are waited for
-    unsigned dn[DVO_PX_PER_THREAD], in_[DVO_PX_PER_THREAD];
-    {
-        const int seg0 = (blk * p.groups_per_block * (DVO_BLOCK / 64) + wave_) * (64 * DVO_PX_PER_THREAD);
+    const DvoPointRec* list = reinterpret_cast<const DvoPointRec*>(prev + p.g.off_list);
+    const int count = p.list_count[p.prev_slot[pair] * DVO_LIST_LEVELS + p.level];
+    const int rec0 = (blk * p.groups_per_block * (DVO_BLOCK / 64) + wave_) * (64 * DVO_PX_PER_THREAD);   // wave-uniform
+    // the records of the next group are requested one group ahead, so their latency is covered by the arithmetic of
+    // the current group and only the dependent tap gathers are waited for
+    uint2 rn[DVO_PX_PER_THREAD];
 #pragma unroll
-        for (int j = 0; j < DVO_PX_PER_THREAD; ++j) {
-            const int idx = seg0 + j * 64 + lane_;
-            const bool in = idx < p.g.npix;
-            dn[j] = in ? (unsigned)depth_prev[idx] : 0u;
-            in_[j] = in ? (unsigned)gray_prev[idx] : 0u;
-        }
+    for (int j = 0; j < DVO_PX_PER_THREAD; ++j) rn[j] = make_uint2(0u, 0u);
+    if (rec0 < count) {
+#pragma unroll
+        for (int j = 0; j < DVO_PX_PER_THREAD; ++j) rn[j] = *reinterpret_cast<const uint2*>(list + rec0 + j * 64 + lane_);
     }
-    int vy0 = 0, ux0 = 0;       // pixel of this lane at the start of the current group (advanced incrementally)
-#if DVO_COMPACT
-    __shared__ uint2 cbuf[DVO_BLOCK / 64][64 * DVO_PX_PER_THREAD];
-#endif
     for (int grp = 0; grp < p.groups_per_block; ++grp) {
-        const int seg = ((blk * p.groups_per_block + grp) * (DVO_BLOCK / 64) + wave_) * (64 * DVO_PX_PER_THREAD);
-        if (seg >= p.g.npix) break;                                       // wave-uniform
-        unsigned dd[DVO_PX_PER_THREAD], ii[DVO_PX_PER_THREAD];
+        const int seg = rec0 + grp * (DVO_BLOCK / 64) * (64 * DVO_PX_PER_THREAD);
+        if (seg >= count) break;                                          // wave-uniform
+        uint2 rc[DVO_PX_PER_THREAD];
 #pragma unroll
-        for (int j = 0; j < DVO_PX_PER_THREAD; ++j) { dd[j] = dn[j]; ii[j] = in_[j]; }
-        if (grp + 1 < p.groups_per_block) {
+        for (int j = 0; j < DVO_PX_PER_THREAD; ++j) rc[j] = rn[j];
+        {
             const int segn = seg + (DVO_BLOCK / 64) * (64 * DVO_PX_PER_THREAD);
+            if (grp + 1 < p.groups_per_block && segn < count) {           // (reads past `count` stay inside DVO_LIST_SLACK)
 #pragma unroll
-            for (int j = 0; j < DVO_PX_PER_THREAD; ++j) {
-                const int idx = segn + j * 64 + lane_;
-                const bool in = idx < p.g.npix;
-                dn[j] = in ? (unsigned)depth_prev[idx] : 0u;
-                in_[j] = in ? (unsigned)gray_prev[idx] : 0u;
+                for (int j = 0; j < DVO_PX_PER_THREAD; ++j) rn[j] = *reinterpret_cast<const uint2*>(list + segn + j * 64 + lane_);
             }
         }
-        if (grp == 0) { vy0 = (seg + lane_) / p.g.w; ux0 = (seg + lane_) - vy0 * p.g.w; }
-        int px[DVO_PX_PER_THREAD], py[DVO_PX_PER_THREAD];
-        {
-            int vy = vy0, ux = ux0;
-#pragma unroll
-            for (int j = 0; j < DVO_PX_PER_THREAD; ++j) {
-                px[j] = ux; py[j] = vy;
-                ux += 64;
-                while (ux >= p.g.w) { ux -= p.g.w; ++vy; }
-            }
-            ux0 = ux + (DVO_BLOCK / 64 - 1) * (64 * DVO_PX_PER_THREAD);      // same lane, next group of this wave
-            vy0 = vy;
-            while (ux0 >= p.g.w) { ux0 -= p.g.w; ++vy0; }
-        }
-#if DVO_COMPACT
-        // Wave-level compaction: ~30 % of the pixels have no depth, and a wave runs a pixel round at full cost as
-        // long as one lane is live.  The depth-valid pixels of the wave's 256 are packed (ballot + mbcnt prefix,
-        // one 8-byte LDS slot each) and dealt back to the lanes densely, so the last round(s) of the group are
-        // empty for every lane and are skipped by the existing per-round branches.
-        {
-            // (only when it buys at least one empty round: a segment with more than 192 live pixels needs all 4)
-            unsigned long long m[DVO_PX_PER_THREAD];
-            unsigned nvalid = 0;
-#pragma unroll
-            for (int j = 0; j < DVO_PX_PER_THREAD; ++j) {
-                m[j] = __builtin_amdgcn_ballot_w64(dd[j] != 0u);
-                nvalid += (unsigned)__builtin_popcountll(m[j]);
-            }
-            if (nvalid <= 64u * (DVO_PX_PER_THREAD - 1) && nvalid > 0u) {          // wave-uniform
-                uint2* cb = cbuf[wave_];
-                unsigned base = 0;
-#pragma unroll
-                for (int j = 0; j < DVO_PX_PER_THREAD; ++j) {
-                    const unsigned pos = base + __builtin_amdgcn_mbcnt_hi((unsigned)(m[j] >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m[j], 0u));
-                    if (dd[j] != 0u) cb[pos] = make_uint2(dd[j] | (ii[j] << 16), (unsigned)px[j] | ((unsigned)py[j] << 16));
-                    base += (unsigned)__builtin_popcountll(m[j]);
-                }
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-#pragma unroll
-                for (int j = 0; j < DVO_PX_PER_THREAD; ++j) {
-                    const unsigned e = (unsigned)(j * 64 + lane_);
-                    const uint2 c = cb[e < nvalid ? e : 0u];
-                    const bool live = e < nvalid;
-                    dd[j] = live ? (c.x & 0xffffu) : 0u;
-                    ii[j] = c.x >> 16;
-                    px[j] = (int)(c.y & 0xffffu);
-                    py[j] = (int)(c.y >> 16);
-                }
-            }
-        }
-#endif
         // phase A for all pixels of the lane, then all tap loads back to back (memory-level parallelism: the
         // dependent gathers of 4 pixels are in flight together), then phase B
         PixelGeo geo[DVO_PX_PER_THREAD];
@@ -639,16 +701,24 @@ __global__ __launch_bounds__(DVO_BLOCK, (VARIANT == 2) ? 2 : DVO_REDUCE_WAVES_PE
         float jv3[(VARIANT == 2) ? DVO_PX_PER_THREAD : 1][6];
 #pragma unroll
         for (int j = 0; j < DVO_PX_PER_THREAD; ++j) {
-            if constexpr (VARIANT == 2) dvo_geo_v3(p.g, cam, p.depth_scale, T, gray_prev, px[j], py[j], dd[j], geo[j], jv3[j]);
-            else dvo_geo<SKEW>(p.g, cam, p.depth_scale, T, px[j], py[j], dd[j], geo[j]);
+            const bool live = (seg + j * 64 + lane_) < count;
+            const unsigned pix = rc[j].y;
+            const unsigned xi = pix & 0xfffu, yi = (pix >> 12) & 0xfffu;
+            if constexpr (VARIANT == 2) {
+                // the numba.cuda kernel converts depth in float32 (dvo_geo_v3): it starts from the raw depth again
+                const unsigned d = live ? (unsigned)depth_prev[yi * (unsigned)p.g.w + xi] : 0u;
+                dvo_geo_v3(p.g, cam, p.depth_scale, T, gray_prev, (int)xi, (int)yi, d, geo[j], jv3[j]);
+            } else {
+                dvo_geo<SKEW>(p.g, cam, T, (float)xi, (float)yi, __uint_as_float(rc[j].x), live, geo[j]);
+            }
             dvo_load_taps(p.g, packed_cur, geo[j], taps[j]);
-            if (VARIANT == 1) taps[j].own = geo[j].ok ? packed_prev[(unsigned)(py[j] * p.g.pitch + px[j])] : 0u;
+            if (VARIANT == 1) taps[j].own = geo[j].ok ? packed_prev[yi * (unsigned)p.g.pitch + xi] : 0u;
         }
 #pragma unroll
         for (int j = 0; j < DVO_PX_PER_THREAD; ++j) {
             if (geo[j].ok) {                                  // depth != 0 (camera_model.py:195) and in bounds
                 PixelOut o;
-                dvo_finish<VARIANT, !SCALE_PASS>(cam, geo[j], taps[j], ii[j], o);
+                dvo_finish<VARIANT, !SCALE_PASS>(cam, geo[j], taps[j], rc[j].y >> 24, o);
                 if constexpr (VARIANT == 2) {
 #pragma unroll
                     for (int k = 0; k < 6; ++k) o.J[k] = jv3[j][k];
@@ -803,8 +873,11 @@ __global__ __launch_bounds__(DVO_BLOCK) void k_dense(const DvoDenseParams p)
         for (int i = 0; i < 12; ++i) T[i] = p.T[i];
         float jpre[6];
         if constexpr (VARIANT == 2) dvo_geo_v3(p.g, p.cam, p.depth_scale, T, gray_prev, ux, vy, d, q, jpre);
-        else if (p.cam.skew0) dvo_geo<false>(p.g, p.cam, p.depth_scale, T, ux, vy, d, q);
-        else dvo_geo<true>(p.g, p.cam, p.depth_scale, T, ux, vy, d, q);
+        else {
+            const float z = (float)((double)d * p.depth_scale);               // camera_model.py:200-201
+            if (p.cam.skew0) dvo_geo<false>(p.g, p.cam, T, (float)ux, (float)vy, z, true, q);
+            else dvo_geo<true>(p.g, p.cam, T, (float)ux, (float)vy, z, true, q);
+        }
         if (q.ok) {
             PixelTaps t;
             dvo_load_taps(p.g, packed_cur, q, t);

@@ -168,7 +168,7 @@ def test_increments_all_pairs_all_iterations_vs_reference_run(hip, frames, golde
                 assert e < 1e-5, (i, e)
                 assert _rel(H, g["H64"][i]) < 1e-6 and _rel(b, g["b64"][i]) < 5e-6
                 assert abs(swr2 - g["sum_r2"][i]) <= 1e-6 * g["sum_r2"][i]
-    assert worst < 2e-6
+    assert worst < 3e-6
 
 
 def test_increments_single_level_trace(hip, frames, golden_dir):
