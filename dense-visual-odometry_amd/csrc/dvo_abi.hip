@@ -289,7 +289,7 @@ int fill_reduce_params(dvo_ctx* ctx, int level, int n_pairs, int w, int h, DvoRe
         int gmax = 16;
         const char* e = getenv("DVO_MAX_GROUPS");
         if (e && atoi(e) > 0) gmax = atoi(e);
-        int target = 4096;
+        int target = 1024;                       // measured on MI355X: small levels gain from fewer, longer workgroups (L2 27 -> 21 us)
         const char* tb = getenv("DVO_TARGET_BLOCKS");
         if (tb && atoi(tb) > 0) target = atoi(tb);
         int gp = (int)(total_groups / target);
