@@ -53,8 +53,6 @@ struct dvo_ctx {
     bool have_camera = false;
     float fx = 0, fy = 0, cx = 0, cy = 0, skew = 0;
     double depth_scale = 0;
-    float ds_hi = 0, ds_lo = 0;
-    int z_fast = 0;
     // scratch (device)
     int* d_prev = nullptr;
     int* d_cur = nullptr;
@@ -181,7 +179,6 @@ DvoLevelCam level_camera(const dvo_ctx* c, int level)
     volatile float t = (-se) - k.cx;
     volatile float ic = t / k.fx;
     k.ia = ia; k.ib = ib; k.ic = ic; k.id = id; k.ie = ie;
-    k.ds_hi = c->ds_hi; k.ds_lo = c->ds_lo; k.z_fast = c->z_fast;
     k.skew0 = (k.s == 0.0f && k.ib == 0.0f) ? 1 : 0;
     return k;
 }
@@ -481,24 +478,6 @@ int dvo_set_camera(dvo_ctx* ctx, float fx, float fy, float cx, float cy, float s
     if (!ctx->have_camera || depth_scale != ctx->depth_scale)
         for (SlotInfo& si : ctx->slots) si.lists = false;      // their valid-point lists hold z for the old scale
     ctx->fx = fx; ctx->fy = fy; ctx->cx = cx; ctx->cy = cy; ctx->skew = skew; ctx->depth_scale = depth_scale;
-    // float32 double-word form of depth_scale; usable in the kernels only if it reproduces the reference's
-    // (float)((double)d * depth_scale) for every 16-bit depth value — checked here, exhaustively.
-    ctx->ds_hi = (float)depth_scale;
-    ctx->ds_lo = (float)(depth_scale - (double)ctx->ds_hi);
-    ctx->z_fast = 1;
-    for (unsigned d = 0; d < 65536u && ctx->z_fast; ++d) {
-        const float ref = (float)((double)d * depth_scale);
-        const float df = (float)d;
-        volatile float ph = df * ctx->ds_hi;
-        const float el = std::fmaf(df, ctx->ds_hi, -ph);
-        volatile float tl = std::fmaf(df, ctx->ds_lo, el);
-        volatile float z = ph + tl;
-        if (!(z == ref)) ctx->z_fast = 0;
-    }
-    {
-        const char* e = getenv("DVO_Z_FLOAT64");           // tests: force the float64 conversion path
-        if (e && e[0] == '1') ctx->z_fast = 0;
-    }
     ctx->have_camera = true;
     return DVO_OK;
 }

@@ -40,8 +40,6 @@ struct DvoPointRec {
 struct DvoLevelCam {
     float fx, fy, cx, cy, s;
     float ia, ib, ic, id, ie;   // inv(K) = [[ia ib ic],[0 id ie],[0 0 1]]
-    float ds_hi, ds_lo;         // depth_scale as a float32 double-word (hi + lo)
-    int z_fast;                 // 1: float32 double-word product verified == (float)((double)d * depth_scale) for all d
     int skew0;                  // 1: skew == 0 (the zero terms of the reference's matrix products are skipped: exact)
 };
 

@@ -207,6 +207,119 @@ __global__ __launch_bounds__(DVO_BLOCK) void k_batch_sobel_pack(const DvoBatchIn
 }
 
 // ------------------------------------------------------------------------------------------------
+// Fused level-0 ingest (images whose width is a multiple of 8 and whose height is even): one pass over the source
+// frame does what k_batch_copy_level0 + k_batch_sobel_pack(0) + k_batch_median_down(1) + the level-0 valid-pixel count
+// do in four.  A workgroup stages a 256 x 8 pixel tile of intensity and depth (plus a one-pixel halo, clamped at the
+// image border: cv2's BORDER_REFLECT of radius 1 and the median's replicate border are both an index clamp) in LDS.
+// ------------------------------------------------------------------------------------------------
+#define ING_TW 256
+#define ING_TH 8
+#define ING_GP (ING_TW / 4 + 2)          // gray tile pitch in words (4 px per word, one halo word each side)
+#define ING_DP (ING_TW / 2 + 2)          // depth tile pitch in words (2 px per word, one halo word each side)
+#define ING_NSEG 40                      // level-0 list segments one tile can touch: 7 * 4096 / 1024 + 2 = 30 at most
+
+__global__ __launch_bounds__(DVO_BLOCK) void k_ingest_level0_fused(const DvoBatchIngestParams p, int segs_per_frame)
+{
+    __shared__ uint32_t gs[(ING_TH + 2) * ING_GP];
+    __shared__ uint32_t ds[(ING_TH + 2) * ING_DP];
+    __shared__ int segc[ING_NSEG];
+    const int f = blockIdx.z, t = threadIdx.x;
+    uint8_t* slot = p.slots + (size_t)p.slot_ids[f] * p.slot_stride;
+    const DvoLevelGeom& g = p.g[0];
+    const int w = g.w, h = g.h;
+    const size_t n = (size_t)g.npix;
+    const bool copy = p.src_gray != nullptr;
+    const uint8_t* sg = copy ? p.src_gray + (size_t)f * n : slot + g.off_gray;
+    const uint16_t* sd = copy ? p.src_depth + (size_t)f * n : reinterpret_cast<const uint16_t*>(slot + g.off_depth);
+    const int x0 = blockIdx.x * ING_TW, y0 = blockIdx.y * ING_TH;
+    if (t < ING_NSEG) segc[t] = 0;
+    for (int i = t; i < (ING_TH + 2) * ING_GP; i += DVO_BLOCK) {
+        const int r = i / ING_GP, c = i - r * ING_GP;
+        const uint8_t* row = sg + (size_t)min(max(y0 - 1 + r, 0), h - 1) * w;
+        const int gx = x0 - 4 + 4 * c;
+        gs[i] = (gx < 0) ? (uint32_t)row[0] * 0x01010101u : (gx >= w) ? (uint32_t)row[w - 1] * 0x01010101u
+                                                                      : *reinterpret_cast<const uint32_t*>(row + gx);
+    }
+    for (int i = t; i < (ING_TH + 2) * ING_DP; i += DVO_BLOCK) {
+        const int r = i / ING_DP, c = i - r * ING_DP;
+        const uint16_t* row = sd + (size_t)min(max(y0 - 1 + r, 0), h - 1) * w;
+        const int gx = x0 - 2 + 2 * c;
+        ds[i] = (gx < 0) ? (uint32_t)row[0] * 0x00010001u : (gx >= w) ? (uint32_t)row[w - 1] * 0x00010001u
+                                                                      : *reinterpret_cast<const uint32_t*>(row + gx);
+    }
+    __syncthreads();
+    // --- level 0: planes, Sobel + pack, valid-pixel counts -------------------------------------------------
+    {
+        const int cg = t & 63, rp = t >> 6;
+        const int x = x0 + 4 * cg;
+        uint8_t* dg = slot + g.off_gray;
+        uint16_t* dd = reinterpret_cast<uint16_t*>(slot + g.off_depth);
+        uint32_t* packed = reinterpret_cast<uint32_t*>(slot + g.off_packed);
+        const int seg_first = (y0 * w + x0) >> 10;
+#pragma unroll
+        for (int dr = 0; dr < 2; ++dr) {
+            const int y = y0 + 2 * rp + dr, tr = 2 * rp + dr + 1;
+            if (x < w && y < h) {
+                int c[3][6];
+#pragma unroll
+                for (int r = 0; r < 3; ++r) {
+                    const uint32_t* q = gs + (tr - 1 + r) * ING_GP + cg;
+                    const uint32_t a = q[0], b = q[1], d = q[2];
+                    c[r][0] = a >> 24;
+                    c[r][1] = b & 0xffu; c[r][2] = (b >> 8) & 0xffu; c[r][3] = (b >> 16) & 0xffu; c[r][4] = b >> 24;
+                    c[r][5] = d & 0xffu;
+                }
+                uint32_t out[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int gx = (c[0][i + 2] + 2 * c[1][i + 2] + c[2][i + 2]) - (c[0][i] + 2 * c[1][i] + c[2][i]);
+                    const int gy = (c[2][i] + 2 * c[2][i + 1] + c[2][i + 2]) - (c[0][i] + 2 * c[0][i + 1] + c[0][i + 2]);
+                    out[i] = (uint32_t)c[1][i + 1] | (((uint32_t)gx & 0xfffu) << 8) | (((uint32_t)gy & 0xfffu) << 20);
+                }
+                *reinterpret_cast<uint4*>(packed + (size_t)y * g.pitch + x) = make_uint4(out[0], out[1], out[2], out[3]);
+                const uint32_t da = ds[tr * ING_DP + 2 * cg + 1], db = ds[tr * ING_DP + 2 * cg + 2];
+                if (copy) {
+                    *reinterpret_cast<uint32_t*>(dg + (size_t)y * w + x) = gs[tr * ING_GP + cg + 1];
+                    *reinterpret_cast<uint2*>(dd + (size_t)y * w + x) = make_uint2(da, db);
+                }
+                const int cnt = ((da & 0xffffu) != 0u) + ((da >> 16) != 0u) + ((db & 0xffffu) != 0u) + ((db >> 16) != 0u);
+                if (cnt) atomicAdd(&segc[((y * w + x) >> 10) - seg_first], cnt);
+            }
+        }
+        __syncthreads();
+        if (t < ING_NSEG && segc[t] != 0) atomicAdd(p.seg_counts + (size_t)f * segs_per_frame + seg_first + t, segc[t]);
+    }
+    // --- level 1: 3x3 median at the even pixels (pyrDownMedianSmooth, utils/image_pyramid.py:19-54) ----------
+    if (p.levels > 1) {
+        const DvoLevelGeom& g1 = p.g[1];
+        uint8_t* g1p = slot + g1.off_gray;
+        uint16_t* d1p = reinterpret_cast<uint16_t*>(slot + g1.off_depth);
+        const int col = t & 127;
+        const int x1 = x0 / 2 + col;
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int r1 = (t >> 7) * 2 + k;
+            const int y1 = y0 / 2 + r1;
+            if (x1 < g1.w && y1 < g1.h) {
+                unsigned a[9], b[9];
+#pragma unroll
+                for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+                    for (int dx = 0; dx < 3; ++dx) {
+                        const int tr = 2 * r1 + dy;                          // tile row of L0 row 2*y1 - 1 + dy
+                        const int pg = 2 * col + dx + 3;                     // gray tile pixel of L0 column 2*x1 - 1 + dx
+                        const int pd = 2 * col + dx + 1;                     // depth tile pixel
+                        a[dy * 3 + dx] = (gs[tr * ING_GP + (pg >> 2)] >> ((pg & 3) * 8)) & 0xffu;
+                        b[dy * 3 + dx] = (ds[tr * ING_DP + (pd >> 1)] >> ((pd & 1) * 16)) & 0xffffu;
+                    }
+                g1p[(size_t)y1 * g1.w + x1] = (uint8_t)median9(a[0], a[1], a[2], a[3], a[4], a[5], a[6], a[7], a[8]);
+                d1p[(size_t)y1 * g1.w + x1] = (uint16_t)median9(b[0], b[1], b[2], b[3], b[4], b[5], b[6], b[7], b[8]);
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // Valid-point lists.  Per frame and level: the pixels with depth != 0, in raster order, one DvoPointRec each.  Three
 // launches for the whole batch and all levels: per-segment counts, exclusive scan per (frame, level), ordered scatter.
 // A segment is DVO_LIST_SEG = 1024 consecutive pixels handled by one wave, lane L taking the 16 consecutive pixels
@@ -229,12 +342,12 @@ __device__ __forceinline__ int wave_sum_i(int v)
 }
 
 template <bool SCATTER>
-__global__ __launch_bounds__(DVO_BLOCK) void k_list_build(const DvoBatchIngestParams p, int segs_per_frame)
+__global__ __launch_bounds__(DVO_BLOCK) void k_list_build(const DvoBatchIngestParams p, int segs_per_frame, int seg_begin)
 {
     __shared__ DvoPointRec stage[SCATTER ? DVO_BLOCK / 64 : 1][SCATTER ? DVO_LIST_SEG : 1];
     const int f = blockIdx.z;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int seg = (int)blockIdx.x * (DVO_BLOCK / 64) + wave;
+    const int seg = seg_begin + (int)blockIdx.x * (DVO_BLOCK / 64) + wave;
     if (seg >= segs_per_frame) return;                                     // wave-uniform
     int sl;
     const int l = list_level_of_segment(p, seg, sl);
@@ -333,21 +446,32 @@ __global__ __launch_bounds__(DVO_BLOCK) void k_list_scan(const DvoBatchIngestPar
 hipError_t dvo_launch_batch_ingest(const DvoBatchIngestParams& p, hipStream_t s)
 {
     const unsigned nf = (unsigned)p.n_frames;
-    if (p.src_gray != nullptr) {
+    int segs = 0;
+    for (int l = 0; l < p.levels; ++l) segs += p.g[l].nseg;
+    const bool aligned = ((reinterpret_cast<uintptr_t>(p.src_gray) | reinterpret_cast<uintptr_t>(p.src_depth)) & 15u) == 0;
+    const bool fused = (p.g[0].w % 8 == 0) && (p.g[0].h % 2 == 0) && aligned && getenv("DVO_INGEST_UNFUSED") == nullptr;
+    if (fused) {
+        hipError_t e = hipMemsetAsync(p.seg_counts, 0, (size_t)nf * segs * sizeof(int), s);    // level-0 counts are accumulated
+        if (e != hipSuccess) return e;
+        dim3 grid((p.g[0].w + ING_TW - 1) / ING_TW, (p.g[0].h + ING_TH - 1) / ING_TH, nf);
+        hipLaunchKernelGGL(k_ingest_level0_fused, grid, dim3(DVO_BLOCK), 0, s, p, segs);
+    } else if (p.src_gray != nullptr) {
         dim3 grid((unsigned)((p.g[0].npix + DVO_BLOCK * 16 - 1) / (DVO_BLOCK * 16)), 1, nf);
         hipLaunchKernelGGL(k_batch_copy_level0, grid, dim3(DVO_BLOCK), 0, s, p);
     }
     for (int l = 0; l < p.levels; ++l) {
         dim3 grid((p.g[l].w + 255) / 256, (p.g[l].h + 3) / 4, nf);
-        if (l > 0) hipLaunchKernelGGL(k_batch_median_down, grid, dim3(DVO_BLOCK), 0, s, p, l);
-        hipLaunchKernelGGL(k_batch_sobel_pack, grid, dim3(DVO_BLOCK), 0, s, p, l);
+        if (l > (fused ? 1 : 0)) hipLaunchKernelGGL(k_batch_median_down, grid, dim3(DVO_BLOCK), 0, s, p, l);
+        if (l > 0 || !fused) hipLaunchKernelGGL(k_batch_sobel_pack, grid, dim3(DVO_BLOCK), 0, s, p, l);
     }
-    int segs = 0;
-    for (int l = 0; l < p.levels; ++l) segs += p.g[l].nseg;
-    const unsigned lb = (unsigned)((segs + DVO_BLOCK / 64 - 1) / (DVO_BLOCK / 64));
-    hipLaunchKernelGGL(k_list_build<false>, dim3(lb, 1, nf), dim3(DVO_BLOCK), 0, s, p, segs);
+    const int seg_begin = fused ? p.g[0].nseg : 0;
+    if (segs > seg_begin) {
+        const unsigned cb = (unsigned)((segs - seg_begin + DVO_BLOCK / 64 - 1) / (DVO_BLOCK / 64));
+        hipLaunchKernelGGL(k_list_build<false>, dim3(cb, 1, nf), dim3(DVO_BLOCK), 0, s, p, segs, seg_begin);
+    }
     hipLaunchKernelGGL(k_list_scan, dim3((unsigned)p.levels, nf), dim3(DVO_BLOCK), 0, s, p, segs);
-    hipLaunchKernelGGL(k_list_build<true>, dim3(lb, 1, nf), dim3(DVO_BLOCK), 0, s, p, segs);
+    const unsigned lb = (unsigned)((segs + DVO_BLOCK / 64 - 1) / (DVO_BLOCK / 64));
+    hipLaunchKernelGGL(k_list_build<true>, dim3(lb, 1, nf), dim3(DVO_BLOCK), 0, s, p, segs, 0);
     return hipGetLastError();
 }
 
@@ -384,20 +508,6 @@ __device__ __forceinline__ void unpack_tap(uint32_t p, float& I, float& gx, floa
     I = (float)(p & 0xffu);
     gx = (float)(((int32_t)(p << 12)) >> 20);
     gy = (float)(((int32_t)p) >> 20);
-}
-
-// z = (float)((double)d * depth_scale) (camera_model.py:200-201).  When the host has verified for all 65536
-// depth values that the float32 double-word product below rounds identically (DvoLevelCam::z_fast), the three
-// slow float64 instructions are replaced by four float32 ones.
-__device__ __forceinline__ float dvo_depth_to_z(unsigned d, double depth_scale, const DvoLevelCam& cam)
-{
-    if (cam.z_fast) {
-        const float df = (float)d;
-        const float ph = df * cam.ds_hi;
-        const float el = fmaf(df, cam.ds_hi, -ph);            // exact rounding error of ph
-        return ph + fmaf(df, cam.ds_lo, el);
-    }
-    return (float)((double)d * depth_scale);
 }
 
 __device__ __forceinline__ float dvo_div_with_rcp(float a, float b, float rb)
@@ -609,9 +719,6 @@ __device__ __forceinline__ void block_reduce_terms(const float* acc, double* out
     if (t >= 30 && t < DVO_STRIDE) out[t] = 0.0;
 }
 
-#ifndef DVO_VCONST
-#define DVO_VCONST 0
-#endif
 #ifndef DVO_REDUCE_WAVES_PER_SIMD
 #define DVO_REDUCE_WAVES_PER_SIMD 4
 #endif
@@ -643,19 +750,7 @@ __global__ __launch_bounds__(DVO_BLOCK, (VARIANT == 2) ? 2 : DVO_REDUCE_WAVES_PE
     float T[12];
 #pragma unroll
     for (int i = 0; i < 12; ++i) T[i] = p.T[pair * 12 + i];
-    DvoLevelCam cam = p.cam;
-#if DVO_VCONST
-    // On gfx950 a VALU instruction with an SGPR source issues at the slow rate (4.4-5.0 vs 3.1-3.4 cycles per wave64
-    // instruction, tools/ubench/valu_asm.hip), and every multiply of the geometry has a constant factor: keep the
-    // pose and the intrinsics in VGPRs.
-    if constexpr (VARIANT != 2) {
-#pragma unroll
-        for (int i = 0; i < 12; ++i) asm volatile("" : "+v"(T[i]));
-        asm volatile("" : "+v"(cam.fx), "+v"(cam.fy), "+v"(cam.cx), "+v"(cam.cy));
-        asm volatile("" : "+v"(cam.ia), "+v"(cam.ic), "+v"(cam.id), "+v"(cam.ie));
-        asm volatile("" : "+v"(cam.ds_hi), "+v"(cam.ds_lo));
-    }
-#endif
+    const DvoLevelCam& cam = p.cam;
     float wpar = 0.0f;
     if (WMODE != 0) wpar = (float)p.wparam[pair];
 

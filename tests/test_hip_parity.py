@@ -644,18 +644,57 @@ def test_fuzz_random_geometry_vs_oracle(seed):
                     assert _rel(_solve(H, b), O.solve_increment(Ho, bo)) < 1e-4 * max(1.0, np.linalg.cond(Ho) / 1e4)
 
 
-def test_float64_depth_conversion_path_matches_fast_path(frames, monkeypatch):
-    """The exact float32 depth conversion is only enabled after an exhaustive host check; the float64 fallback
-    (forced here) must give bit-identical records."""
+def test_fused_level0_ingest_equals_separate_kernels(frames, monkeypatch):
+    """Images with width % 8 == 0 and even height take the fused level-0 ingest kernel (copy + Sobel/pack + level-1
+    median + valid-pixel counts in one pass); DVO_INGEST_UNFUSED forces the separate kernels every other geometry
+    uses.  Pyramids, gradients and normal-equation records (i.e. the valid-point lists) must be bit-identical, for
+    the single-frame upload (level 0 copied into the slot by the host call) and the batched one."""
     import dvo_amd
     T = O.Pose.from_xi(np.array([0.002, -0.007, -0.011, 0.005, 0.0065, 0.0034])).matrix()[None]
-    recs = []
-    for force in ("0", "1"):
-        monkeypatch.setenv("DVO_Z_FLOAT64", force)
-        with dvo_amd.HipContext(max_w=640, max_h=480, max_levels=2, n_slots=2, max_pairs=1) as ctx:
+    got = []
+    for unfused in (False, True):
+        if unfused:
+            monkeypatch.setenv("DVO_INGEST_UNFUSED", "1")
+        else:
+            monkeypatch.delenv("DVO_INGEST_UNFUSED", raising=False)
+        with dvo_amd.HipContext(max_w=640, max_h=480, max_levels=4, n_slots=4, max_pairs=1) as ctx:
             K = frames["K"]
             ctx.set_camera(K[0, 0], K[1, 1], K[0, 2], K[1, 2], K[0, 1], frames["depth_scale"])
-            ctx.upload_frame(0, frames["gray"][0], frames["depth"][0], 2)
-            ctx.upload_frame(1, frames["gray"][1], frames["depth"][1], 2)
-            recs.append(ctx.normal_equations(1, [0], [1], T))
-    assert np.array_equal(recs[0], recs[1])
+            ctx.upload_frame(0, frames["gray"][0], frames["depth"][0], 4)
+            ctx.upload_frame(1, frames["gray"][1], frames["depth"][1], 4)
+            ctx.upload_frames([2, 3], frames["gray"][2:4], frames["depth"][2:4], 4)
+            ctx.synchronize()
+            levels = [ctx.download_level(s, l) for s in range(4) for l in range(4)]
+            recs = [ctx.normal_equations(l, [0], [1], T) for l in range(4)] + [ctx.normal_equations(l, [2], [3], T) for l in range(4)]
+            got.append((levels, recs))
+    for a, b in zip(got[0][0], got[1][0]):
+        for k in ("gray", "depth", "gx", "gy"):
+            assert np.array_equal(a[k], b[k]), k
+    for a, b in zip(got[0][1], got[1][1]):
+        assert np.array_equal(a, b)
+
+
+def test_frames_uploaded_before_the_camera_must_be_uploaded_again(frames):
+    """The valid-point lists built at ingest hold z = depth * depth_scale: a frame uploaded before dvo_set_camera (or
+    under another depth_scale) still has its pyramid, but the alignment entry points refuse it (BAD_STATE)."""
+    import dvo_amd
+    from dvo_amd import _cabi
+    T = np.eye(4, dtype=np.float32)[None, :3]
+    K = frames["K"]
+    with dvo_amd.HipContext(max_w=640, max_h=480, max_levels=2, n_slots=2, max_pairs=1) as ctx:
+        ctx.upload_frame(0, frames["gray"][0], frames["depth"][0], 2)
+        ctx.upload_frame(1, frames["gray"][1], frames["depth"][1], 2)
+        assert ctx.download_level(0, 1)["gray"].shape == (240, 320)
+        ctx.set_camera(K[0, 0], K[1, 1], K[0, 2], K[1, 2], K[0, 1], frames["depth_scale"])
+        with pytest.raises(_cabi.DVOHipError) as e:
+            ctx.normal_equations(0, [0], [1], T)
+        assert e.value.code == -5
+        ctx.upload_frame(0, frames["gray"][0], frames["depth"][0], 2)
+        ctx.upload_frame(1, frames["gray"][1], frames["depth"][1], 2)
+        ref = ctx.normal_equations(0, [0], [1], T)
+        ctx.set_camera(K[0, 0], K[1, 1], K[0, 2], K[1, 2], K[0, 1], 2.0 * frames["depth_scale"])
+        with pytest.raises(_cabi.DVOHipError):
+            ctx.normal_equations(0, [0], [1], T)
+        ctx.set_camera(K[0, 0] * 1.01, K[1, 1], K[0, 2], K[1, 2], K[0, 1], 2.0 * frames["depth_scale"])   # intrinsics only: lists stay valid
+        ctx.upload_frame(0, frames["gray"][0], frames["depth"][0], 2)
+        assert ctx.normal_equations(0, [0], [1], T).shape == ref.shape
