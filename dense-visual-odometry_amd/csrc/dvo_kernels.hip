@@ -21,20 +21,24 @@
 // ================================================================================================
 // K1: median 3x3 + decimate
 // ================================================================================================
-#define DVO_CSWAP(a, b) { unsigned _t = min(a, b); b = max(a, b); a = _t; }
+__device__ __forceinline__ unsigned umed3(unsigned a, unsigned b, unsigned c)
+{
+    unsigned r;
+    asm("v_med3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+__device__ __forceinline__ unsigned umin3(unsigned a, unsigned b, unsigned c) { return min(min(a, b), c); }     // v_min3_u32
+__device__ __forceinline__ unsigned umax3(unsigned a, unsigned b, unsigned c) { return max(max(a, b), c); }     // v_max3_u32
 
+// Median of nine as 13 three-operand instructions: sort each triple (min3 / med3 / max3), then the median of
+// {largest of the minima, median of the medians, smallest of the maxima}.
 __device__ __forceinline__ unsigned median9(unsigned p0, unsigned p1, unsigned p2, unsigned p3, unsigned p4,
                                             unsigned p5, unsigned p6, unsigned p7, unsigned p8)
 {
-    // 19-exchange median-of-9 network
-    DVO_CSWAP(p1, p2); DVO_CSWAP(p4, p5); DVO_CSWAP(p7, p8);
-    DVO_CSWAP(p0, p1); DVO_CSWAP(p3, p4); DVO_CSWAP(p6, p7);
-    DVO_CSWAP(p1, p2); DVO_CSWAP(p4, p5); DVO_CSWAP(p7, p8);
-    DVO_CSWAP(p0, p3); DVO_CSWAP(p5, p8); DVO_CSWAP(p4, p7);
-    DVO_CSWAP(p3, p6); DVO_CSWAP(p1, p4); DVO_CSWAP(p2, p5);
-    DVO_CSWAP(p4, p7); DVO_CSWAP(p4, p2); DVO_CSWAP(p6, p4);
-    DVO_CSWAP(p4, p2);
-    return p4;
+    const unsigned lo = umax3(umin3(p0, p1, p2), umin3(p3, p4, p5), umin3(p6, p7, p8));
+    const unsigned mi = umed3(umed3(p0, p1, p2), umed3(p3, p4, p5), umed3(p6, p7, p8));
+    const unsigned hi = umin3(umax3(p0, p1, p2), umax3(p3, p4, p5), umax3(p6, p7, p8));
+    return umed3(lo, mi, hi);
 }
 
 __global__ __launch_bounds__(DVO_BLOCK) void k_unpack(const uint32_t* __restrict__ packed, int w, int h, int pitch,
@@ -207,50 +211,113 @@ __global__ __launch_bounds__(DVO_BLOCK) void k_batch_sobel_pack(const DvoBatchIn
 }
 
 // ------------------------------------------------------------------------------------------------
-// Fused level-0 ingest (images whose width is a multiple of 8 and whose height is even): one pass over the source
-// frame does what k_batch_copy_level0 + k_batch_sobel_pack(0) + k_batch_median_down(1) + the level-0 valid-pixel count
-// do in four.  A workgroup stages a 256 x 8 pixel tile of intensity and depth (plus a one-pixel halo, clamped at the
-// image border: cv2's BORDER_REFLECT of radius 1 and the median's replicate border are both an index clamp) in LDS.
+// Fused per-level ingest (levels whose width is a multiple of 16 and whose height is even): one pass over level L does
+// what k_batch_copy_level0 (L = 0) + k_batch_sobel_pack(L) + k_batch_median_down(L + 1) + the valid-pixel count of
+// level L do in four.  A workgroup stages a 256 x 8 pixel tile of intensity and depth (plus a one-pixel halo, clamped
+// at the image border: cv2's BORDER_REFLECT of radius 1 and the median's replicate border are both an index clamp)
+// in LDS.
 // ------------------------------------------------------------------------------------------------
-#define ING_TW 256
-#define ING_TH 8
-#define ING_GP (ING_TW / 4 + 2)          // gray tile pitch in words (4 px per word, one halo word each side)
-#define ING_DP (ING_TW / 2 + 2)          // depth tile pitch in words (2 px per word, one halo word each side)
-#define ING_NSEG 40                      // level-0 list segments one tile can touch: 7 * 4096 / 1024 + 2 = 30 at most
+// Tile: ING_TW pixels wide (256, 128, 64 or 32: the launch picks the width that wastes the fewest lanes on the level's
+// row length), 2048 / ING_TW rows; 64 4-pixel column groups x row pairs = 256 threads either way.
 
-__global__ __launch_bounds__(DVO_BLOCK) void k_ingest_level0_fused(const DvoBatchIngestParams p, int segs_per_frame)
+template <int ING_TW>
+__global__ __launch_bounds__(DVO_BLOCK) void k_ingest_level_fused(const DvoBatchIngestParams p, int segs_per_frame, int level,
+                                                                  int seg_base)
 {
-    __shared__ uint32_t gs[(ING_TH + 2) * ING_GP];
-    __shared__ uint32_t ds[(ING_TH + 2) * ING_DP];
+    constexpr int ING_TH = 2048 / ING_TW;
+    constexpr int ING_PAD = 4;                      // pad words left of a tile row (only the last is a halo): rows stay 16-byte aligned
+    constexpr int ING_GP = ING_TW / 4 + 2 * ING_PAD;    // gray tile pitch in words (4 px per word)
+    constexpr int ING_DP = ING_TW / 2 + 2 * ING_PAD;    // depth tile pitch in words (2 px per word)
+    constexpr int CGN = ING_TW / 4;                 // 4-pixel column groups per tile row
+    constexpr int ING_NSEG = 4 * (ING_TH - 1) + 2;  // list segments one tile can touch: (rows - 1) * 4096 / 1024 + 2 (<= 254)
+    constexpr int ROWS = ING_TH + 2;
+    constexpr int GQ = ING_TW / 16, DQ = ING_TW / 8;            // 16-byte pieces per tile row (intensity, depth)
+    constexpr int NQ = ROWS * (GQ + DQ);
+    constexpr int NI = (NQ + DVO_BLOCK - 1) / DVO_BLOCK;        // interior load rounds
+    constexpr int NH = (4 * ROWS + DVO_BLOCK - 1) / DVO_BLOCK;  // halo load rounds (2 planes x 2 sides x rows)
+    __shared__ __attribute__((aligned(16))) uint32_t gs[ROWS * ING_GP];
+    __shared__ __attribute__((aligned(16))) uint32_t ds[ROWS * ING_DP];
     __shared__ int segc[ING_NSEG];
     const int f = blockIdx.z, t = threadIdx.x;
     uint8_t* slot = p.slots + (size_t)p.slot_ids[f] * p.slot_stride;
-    const DvoLevelGeom& g = p.g[0];
+    const DvoLevelGeom& g = p.g[level];
     const int w = g.w, h = g.h;
     const size_t n = (size_t)g.npix;
-    const bool copy = p.src_gray != nullptr;
+    const bool copy = (level == 0) && (p.src_gray != nullptr);     // else the level's planes are already in the slot
     const uint8_t* sg = copy ? p.src_gray + (size_t)f * n : slot + g.off_gray;
     const uint16_t* sd = copy ? p.src_depth + (size_t)f * n : reinterpret_cast<const uint16_t*>(slot + g.off_depth);
     const int x0 = blockIdx.x * ING_TW, y0 = blockIdx.y * ING_TH;
     if (t < ING_NSEG) segc[t] = 0;
-    for (int i = t; i < (ING_TH + 2) * ING_GP; i += DVO_BLOCK) {
-        const int r = i / ING_GP, c = i - r * ING_GP;
-        const uint8_t* row = sg + (size_t)min(max(y0 - 1 + r, 0), h - 1) * w;
-        const int gx = x0 - 4 + 4 * c;
-        gs[i] = (gx < 0) ? (uint32_t)row[0] * 0x01010101u : (gx >= w) ? (uint32_t)row[w - 1] * 0x01010101u
-                                                                      : *reinterpret_cast<const uint32_t*>(row + gx);
-    }
-    for (int i = t; i < (ING_TH + 2) * ING_DP; i += DVO_BLOCK) {
-        const int r = i / ING_DP, c = i - r * ING_DP;
-        const uint16_t* row = sd + (size_t)min(max(y0 - 1 + r, 0), h - 1) * w;
-        const int gx = x0 - 2 + 2 * c;
-        ds[i] = (gx < 0) ? (uint32_t)row[0] * 0x00010001u : (gx >= w) ? (uint32_t)row[w - 1] * 0x00010001u
-                                                                      : *reinterpret_cast<const uint32_t*>(row + gx);
+    // Tile load: all global loads of a thread are issued before its first LDS store, 16 bytes per lane for the interior
+    // (w % 16 == 0, so a piece is entirely inside the image or entirely right of it) — enough bytes in flight per CU to
+    // stream from HBM.
+    {
+        uint4 v[NI];
+        uint32_t hv[NH];
+#pragma unroll
+        for (int k = 0; k < NI; ++k) {
+            const int i = t + k * DVO_BLOCK;
+            v[k] = make_uint4(0u, 0u, 0u, 0u);
+            if (i < ROWS * GQ) {
+                const int r = i / GQ, c = i - r * GQ;
+                const uint8_t* row = sg + (size_t)min(max(y0 - 1 + r, 0), h - 1) * w;
+                const int gx = x0 + 16 * c;
+                if (gx < w) v[k] = *reinterpret_cast<const uint4*>(row + gx);
+                else { const uint32_t e = (uint32_t)row[w - 1] * 0x01010101u; v[k] = make_uint4(e, e, e, e); }
+            } else if (i < NQ) {
+                const int j = i - ROWS * GQ;
+                const int r = j / DQ, c = j - r * DQ;
+                const uint16_t* row = sd + (size_t)min(max(y0 - 1 + r, 0), h - 1) * w;
+                const int gx = x0 + 8 * c;
+                if (gx < w) v[k] = *reinterpret_cast<const uint4*>(row + gx);
+                else { const uint32_t e = (uint32_t)row[w - 1] * 0x00010001u; v[k] = make_uint4(e, e, e, e); }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < NH; ++k) {
+            const int i = t + k * DVO_BLOCK;
+            hv[k] = 0u;
+            if (i < 4 * ROWS) {
+                const int r = i >> 2, side = i & 1, plane = (i >> 1) & 1;
+                const size_t ro = (size_t)min(max(y0 - 1 + r, 0), h - 1) * w;
+                const int gx = side ? x0 + ING_TW : x0 - (plane ? 2 : 4);       // first pixel of the halo word
+                if (plane == 0) {
+                    const uint8_t* row = sg + ro;
+                    hv[k] = (gx < 0) ? (uint32_t)row[0] * 0x01010101u : (gx >= w) ? (uint32_t)row[w - 1] * 0x01010101u
+                                                                                  : *reinterpret_cast<const uint32_t*>(row + gx);
+                } else {
+                    const uint16_t* row = sd + ro;
+                    hv[k] = (gx < 0) ? (uint32_t)row[0] * 0x00010001u : (gx >= w) ? (uint32_t)row[w - 1] * 0x00010001u
+                                                                                  : *reinterpret_cast<const uint32_t*>(row + gx);
+                }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < NI; ++k) {
+            const int i = t + k * DVO_BLOCK;
+            if (i < ROWS * GQ) {
+                const int r = i / GQ, c = i - r * GQ;
+                *reinterpret_cast<uint4*>(gs + r * ING_GP + ING_PAD + 4 * c) = v[k];
+            } else if (i < NQ) {
+                const int j = i - ROWS * GQ;
+                const int r = j / DQ, c = j - r * DQ;
+                *reinterpret_cast<uint4*>(ds + r * ING_DP + ING_PAD + 4 * c) = v[k];
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < NH; ++k) {
+            const int i = t + k * DVO_BLOCK;
+            if (i < 4 * ROWS) {
+                const int r = i >> 2, side = i & 1, plane = (i >> 1) & 1;
+                if (plane == 0) gs[r * ING_GP + (side ? ING_PAD + ING_TW / 4 : ING_PAD - 1)] = hv[k];
+                else ds[r * ING_DP + (side ? ING_PAD + ING_TW / 2 : ING_PAD - 1)] = hv[k];
+            }
+        }
     }
     __syncthreads();
-    // --- level 0: planes, Sobel + pack, valid-pixel counts -------------------------------------------------
+    // --- this level: planes (when they come from outside), Sobel + pack, valid-pixel counts ------------------
     {
-        const int cg = t & 63, rp = t >> 6;
+        const int cg = t % CGN, rp = t / CGN;
         const int x = x0 + 4 * cg;
         uint8_t* dg = slot + g.off_gray;
         uint16_t* dd = reinterpret_cast<uint16_t*>(slot + g.off_depth);
@@ -263,7 +330,7 @@ __global__ __launch_bounds__(DVO_BLOCK) void k_ingest_level0_fused(const DvoBatc
                 int c[3][6];
 #pragma unroll
                 for (int r = 0; r < 3; ++r) {
-                    const uint32_t* q = gs + (tr - 1 + r) * ING_GP + cg;
+                    const uint32_t* q = gs + (tr - 1 + r) * ING_GP + ING_PAD - 1 + cg;
                     const uint32_t a = q[0], b = q[1], d = q[2];
                     c[r][0] = a >> 24;
                     c[r][1] = b & 0xffu; c[r][2] = (b >> 8) & 0xffu; c[r][3] = (b >> 16) & 0xffu; c[r][4] = b >> 24;
@@ -277,9 +344,9 @@ __global__ __launch_bounds__(DVO_BLOCK) void k_ingest_level0_fused(const DvoBatc
                     out[i] = (uint32_t)c[1][i + 1] | (((uint32_t)gx & 0xfffu) << 8) | (((uint32_t)gy & 0xfffu) << 20);
                 }
                 *reinterpret_cast<uint4*>(packed + (size_t)y * g.pitch + x) = make_uint4(out[0], out[1], out[2], out[3]);
-                const uint32_t da = ds[tr * ING_DP + 2 * cg + 1], db = ds[tr * ING_DP + 2 * cg + 2];
+                const uint32_t da = ds[tr * ING_DP + ING_PAD + 2 * cg], db = ds[tr * ING_DP + ING_PAD + 2 * cg + 1];
                 if (copy) {
-                    *reinterpret_cast<uint32_t*>(dg + (size_t)y * w + x) = gs[tr * ING_GP + cg + 1];
+                    *reinterpret_cast<uint32_t*>(dg + (size_t)y * w + x) = gs[tr * ING_GP + ING_PAD + cg];
                     *reinterpret_cast<uint2*>(dd + (size_t)y * w + x) = make_uint2(da, db);
                 }
                 const int cnt = ((da & 0xffffu) != 0u) + ((da >> 16) != 0u) + ((db & 0xffffu) != 0u) + ((db >> 16) != 0u);
@@ -287,18 +354,18 @@ __global__ __launch_bounds__(DVO_BLOCK) void k_ingest_level0_fused(const DvoBatc
             }
         }
         __syncthreads();
-        if (t < ING_NSEG && segc[t] != 0) atomicAdd(p.seg_counts + (size_t)f * segs_per_frame + seg_first + t, segc[t]);
+        if (t < ING_NSEG && segc[t] != 0) atomicAdd(p.seg_counts + (size_t)f * segs_per_frame + seg_base + seg_first + t, segc[t]);
     }
-    // --- level 1: 3x3 median at the even pixels (pyrDownMedianSmooth, utils/image_pyramid.py:19-54) ----------
-    if (p.levels > 1) {
-        const DvoLevelGeom& g1 = p.g[1];
+    // --- next level: 3x3 median at the even pixels (pyrDownMedianSmooth, utils/image_pyramid.py:19-54) --------
+    if (level + 1 < p.levels) {
+        const DvoLevelGeom& g1 = p.g[level + 1];
         uint8_t* g1p = slot + g1.off_gray;
         uint16_t* d1p = reinterpret_cast<uint16_t*>(slot + g1.off_depth);
-        const int col = t & 127;
+        const int col = t % (ING_TW / 2);
         const int x1 = x0 / 2 + col;
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
-            const int r1 = (t >> 7) * 2 + k;
+            const int r1 = (t / (ING_TW / 2)) * 2 + k;
             const int y1 = y0 / 2 + r1;
             if (x1 < g1.w && y1 < g1.h) {
                 unsigned a[9], b[9];
@@ -307,8 +374,8 @@ __global__ __launch_bounds__(DVO_BLOCK) void k_ingest_level0_fused(const DvoBatc
 #pragma unroll
                     for (int dx = 0; dx < 3; ++dx) {
                         const int tr = 2 * r1 + dy;                          // tile row of L0 row 2*y1 - 1 + dy
-                        const int pg = 2 * col + dx + 3;                     // gray tile pixel of L0 column 2*x1 - 1 + dx
-                        const int pd = 2 * col + dx + 1;                     // depth tile pixel
+                        const int pg = 2 * col + dx - 1 + 4 * ING_PAD;       // gray tile pixel of column 2*x1 - 1 + dx
+                        const int pd = 2 * col + dx - 1 + 2 * ING_PAD;       // depth tile pixel
                         a[dy * 3 + dx] = (gs[tr * ING_GP + (pg >> 2)] >> ((pg & 3) * 8)) & 0xffu;
                         b[dy * 3 + dx] = (ds[tr * ING_DP + (pd >> 1)] >> ((pd & 1) * 16)) & 0xffffu;
                     }
@@ -342,13 +409,14 @@ __device__ __forceinline__ int wave_sum_i(int v)
 }
 
 template <bool SCATTER>
-__global__ __launch_bounds__(DVO_BLOCK) void k_list_build(const DvoBatchIngestParams p, int segs_per_frame, int seg_begin)
+__global__ __launch_bounds__(DVO_BLOCK) void k_list_build(const DvoBatchIngestParams p, int segs_per_frame, int seg_begin,
+                                                          int seg_end)
 {
     __shared__ DvoPointRec stage[SCATTER ? DVO_BLOCK / 64 : 1][SCATTER ? DVO_LIST_SEG : 1];
     const int f = blockIdx.z;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int seg = seg_begin + (int)blockIdx.x * (DVO_BLOCK / 64) + wave;
-    if (seg >= segs_per_frame) return;                                     // wave-uniform
+    if (seg >= seg_end) return;                                            // wave-uniform
     int sl;
     const int l = list_level_of_segment(p, seg, sl);
     const DvoLevelGeom& g = p.g[l];
@@ -449,29 +517,49 @@ hipError_t dvo_launch_batch_ingest(const DvoBatchIngestParams& p, hipStream_t s)
     int segs = 0;
     for (int l = 0; l < p.levels; ++l) segs += p.g[l].nseg;
     const bool aligned = ((reinterpret_cast<uintptr_t>(p.src_gray) | reinterpret_cast<uintptr_t>(p.src_depth)) & 15u) == 0;
-    const bool fused = (p.g[0].w % 8 == 0) && (p.g[0].h % 2 == 0) && aligned && getenv("DVO_INGEST_UNFUSED") == nullptr;
-    if (fused) {
-        hipError_t e = hipMemsetAsync(p.seg_counts, 0, (size_t)nf * segs * sizeof(int), s);    // level-0 counts are accumulated
-        if (e != hipSuccess) return e;
-        dim3 grid((p.g[0].w + ING_TW - 1) / ING_TW, (p.g[0].h + ING_TH - 1) / ING_TH, nf);
-        hipLaunchKernelGGL(k_ingest_level0_fused, grid, dim3(DVO_BLOCK), 0, s, p, segs);
-    } else if (p.src_gray != nullptr) {
-        dim3 grid((unsigned)((p.g[0].npix + DVO_BLOCK * 16 - 1) / (DVO_BLOCK * 16)), 1, nf);
-        hipLaunchKernelGGL(k_batch_copy_level0, grid, dim3(DVO_BLOCK), 0, s, p);
-    }
+    const bool allow_fused = getenv("DVO_INGEST_UNFUSED") == nullptr;
+    hipError_t e = hipMemsetAsync(p.seg_counts, 0, (size_t)nf * segs * sizeof(int), s);    // fused levels accumulate their counts
+    if (e != hipSuccess) return e;
+    bool have_planes = (p.src_gray == nullptr);          // planes of the current level already in the slots?
+    int seg_base = 0;
     for (int l = 0; l < p.levels; ++l) {
-        dim3 grid((p.g[l].w + 255) / 256, (p.g[l].h + 3) / 4, nf);
-        if (l > (fused ? 1 : 0)) hipLaunchKernelGGL(k_batch_median_down, grid, dim3(DVO_BLOCK), 0, s, p, l);
-        if (l > 0 || !fused) hipLaunchKernelGGL(k_batch_sobel_pack, grid, dim3(DVO_BLOCK), 0, s, p, l);
-    }
-    const int seg_begin = fused ? p.g[0].nseg : 0;
-    if (segs > seg_begin) {
-        const unsigned cb = (unsigned)((segs - seg_begin + DVO_BLOCK / 64 - 1) / (DVO_BLOCK / 64));
-        hipLaunchKernelGGL(k_list_build<false>, dim3(cb, 1, nf), dim3(DVO_BLOCK), 0, s, p, segs, seg_begin);
+        const DvoLevelGeom& g = p.g[l];
+        const bool fused = allow_fused && (g.w % 16 == 0) && (g.h % 2 == 0) && (l > 0 || aligned);
+        dim3 grid((g.w + 255) / 256, (g.h + 3) / 4, nf);
+        if (fused) {
+            // tile width with the best lane utilisation on this row length (ties: the wider tile)
+            int tw = 256;
+            double best = 0.0;
+            for (int c = 256; c >= 32; c >>= 1) {
+                const double u = (double)g.w / (double)(((g.w + c - 1) / c) * c);
+                if (u > best + 1e-9) { best = u; tw = c; }
+            }
+            const int th = 2048 / tw;
+            dim3 fg((g.w + tw - 1) / tw, (g.h + th - 1) / th, nf);
+            if (tw == 256) hipLaunchKernelGGL(k_ingest_level_fused<256>, fg, dim3(DVO_BLOCK), 0, s, p, segs, l, seg_base);
+            else if (tw == 128) hipLaunchKernelGGL(k_ingest_level_fused<128>, fg, dim3(DVO_BLOCK), 0, s, p, segs, l, seg_base);
+            else if (tw == 64) hipLaunchKernelGGL(k_ingest_level_fused<64>, fg, dim3(DVO_BLOCK), 0, s, p, segs, l, seg_base);
+            else hipLaunchKernelGGL(k_ingest_level_fused<32>, fg, dim3(DVO_BLOCK), 0, s, p, segs, l, seg_base);
+        } else {
+            if (l == 0 && !have_planes) {
+                dim3 cg((unsigned)((g.npix + DVO_BLOCK * 16 - 1) / (DVO_BLOCK * 16)), 1, nf);
+                hipLaunchKernelGGL(k_batch_copy_level0, cg, dim3(DVO_BLOCK), 0, s, p);
+            }
+            hipLaunchKernelGGL(k_batch_sobel_pack, grid, dim3(DVO_BLOCK), 0, s, p, l);
+            const unsigned cb = (unsigned)((g.nseg + DVO_BLOCK / 64 - 1) / (DVO_BLOCK / 64));
+            hipLaunchKernelGGL(k_list_build<false>, dim3(cb, 1, nf), dim3(DVO_BLOCK), 0, s, p, segs, seg_base, seg_base + g.nseg);
+            if (l + 1 < p.levels) {
+                const DvoLevelGeom& gn = p.g[l + 1];
+                dim3 mg((gn.w + 255) / 256, (gn.h + 3) / 4, nf);
+                hipLaunchKernelGGL(k_batch_median_down, mg, dim3(DVO_BLOCK), 0, s, p, l + 1);
+            }
+        }
+        have_planes = true;
+        seg_base += g.nseg;
     }
     hipLaunchKernelGGL(k_list_scan, dim3((unsigned)p.levels, nf), dim3(DVO_BLOCK), 0, s, p, segs);
     const unsigned lb = (unsigned)((segs + DVO_BLOCK / 64 - 1) / (DVO_BLOCK / 64));
-    hipLaunchKernelGGL(k_list_build<true>, dim3(lb, 1, nf), dim3(DVO_BLOCK), 0, s, p, segs, 0);
+    hipLaunchKernelGGL(k_list_build<true>, dim3(lb, 1, nf), dim3(DVO_BLOCK), 0, s, p, segs, 0, segs);
     return hipGetLastError();
 }
 

@@ -22,7 +22,7 @@ for f in glob.glob(root + "/trace/**/*kernel_stats.csv", recursive=True):
     print("  %-64s %8s %14s %12s %12s %12s" % ("kernel", "calls", "total_us", "avg_us", "min_us", "max_us"))
     for r in rows:
         n = r.get("Name", "")
-        if "k_reduce" in n or n.startswith("k_") or "k_batch" in n:
+        if n.startswith(("k_", "void k_")):
             print("  %-64s %8s %14.1f %12.2f %12.2f %12.2f" % (short(n), r["Calls"], float(r["TotalDurationNs"]) / 1e3,
                                                             float(r["AverageNs"]) / 1e3, float(r["MinNs"]) / 1e3, float(r["MaxNs"]) / 1e3))
 
