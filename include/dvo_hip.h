@@ -73,8 +73,8 @@ typedef enum dvo_weight_mode {
 
 /* ---- lifetime -------------------------------------------------------------------------------- */
 
-/* Creates a context on HIP device `device` with `n_slots` frame slots sized for max_w x max_h images and
- * up to max_levels pyramid levels, and scratch for up to max_pairs frame pairs per call.
+/* Creates a context on HIP device `device` with `n_slots` frame slots sized for max_w x max_h images (at most
+ * 4096 x 4096) and up to max_levels pyramid levels, and scratch for up to max_pairs frame pairs per call.
  * Counterpart of RobustDVOGPU.__init__ pre-allocating its pyramids
  * (core/robust_dense_visual_odometry/gpu_robust_dense_visual_odometry.py:17-47). */
 int dvo_create(int device, int max_w, int max_h, int max_levels, int n_slots, int max_pairs, dvo_ctx** out);
@@ -88,7 +88,11 @@ int dvo_synchronize(dvo_ctx* ctx);
 
 /* ---- camera (camera_model.py:17-79) ------------------------------------------------------------ */
 
-/* Level-0 intrinsics; level L intrinsics follow RGBDCameraModel.at (camera_model.py:62-79). */
+/* Level-0 intrinsics; level L intrinsics follow RGBDCameraModel.at (camera_model.py:62-79).
+ * Call it BEFORE uploading frames (the reference takes the camera model in the constructor): the ingest stores
+ * z = depth * depth_scale with every depth-valid pixel.  A frame uploaded earlier, or under another depth_scale, keeps
+ * its pyramid but the alignment calls refuse it as the previous frame of a pair (DVO_ERR_BAD_STATE) until it is
+ * uploaded again; changing only the intrinsics needs no re-upload. */
 int dvo_set_camera(dvo_ctx* ctx, float fx, float fy, float cx, float cy, float skew, double depth_scale);
 /* Writes the 3x4 float32 level intrinsics the kernels use (for tests / hosts that want to cross-check). */
 int dvo_get_level_intrinsics(const dvo_ctx* ctx, int level, float* k3x4);
@@ -97,12 +101,13 @@ int dvo_get_level_intrinsics(const dvo_ctx* ctx, int level, float* k3x4);
  * (cpu_robust_dense_visual_odometry.py:44-77; utils/image_pyramid.py:19-54; utils/jacobian.py:47-73) */
 
 /* Host images -> slot: H2D copy, then on device: (median3 + 2x decimate) per level for gray and depth,
- * Sobel3x3/BORDER_REFLECT of every gray level packed with the intensity. */
+ * Sobel3x3/BORDER_REFLECT of every gray level packed with the intensity, and per level the list of depth-valid
+ * pixels (camera_model.py:195 mask, :200-201 z) the Gauss-Newton iterations work on. */
 int dvo_upload_frame(dvo_ctx* ctx, int slot, const uint8_t* gray, const uint16_t* depth, int w, int h, int levels);
 /* Same, but gray/depth are DEVICE pointers already resident in HBM (async on the ctx stream). */
 int dvo_upload_frame_device(dvo_ctx* ctx, int slot, const void* d_gray, const void* d_depth, int w, int h, int levels);
-/* Batched form: n_frames images, contiguous [n][h][w] DEVICE arrays, into the listed (distinct) slots; three
- * launches per pyramid level for the whole batch (async on the ctx stream). */
+/* Batched form: n_frames images, contiguous [n][h][w] DEVICE arrays, into the listed (distinct) slots; one fused
+ * launch per pyramid level plus three for the valid-pixel lists, for the whole batch (async on the ctx stream). */
 int dvo_upload_frames_device(dvo_ctx* ctx, int n_frames, const int* slots, const void* d_gray, const void* d_depth,
                              int w, int h, int levels);
 /* Batched form for HOST images: contiguous [n][h][w] arrays, two large H2D copies + the batched build.  With
