@@ -89,6 +89,13 @@ struct dvo_ctx {
     hipEvent_t tm_a = nullptr, tm_b = nullptr;
     hipEvent_t ev_staging = nullptr;
     hipEvent_t ev_order = nullptr;       // dvo_wait_for: marks "everything enqueued on this ctx so far"
+    // dvo_set_upload_peer: host->device copies of dvo_upload_frames go to the peer's copy stream (one in-order queue
+    // for all contexts that share the PCIe link), the ctx stream waits for them by event
+    hipStream_t copy_stream = nullptr;
+    dvo_ctx* upload_peer = nullptr;
+    hipEvent_t ev_uploaded = nullptr;    // recorded on the copy stream after this ctx's copies
+    hipEvent_t ev_ingested = nullptr;    // recorded on the ctx stream after the ingest kernels that read the staging area
+    bool ingested_recorded = false;
     bool staging_in_flight = false;
     struct PendingEv { hipEvent_t a, b; int level; };
     std::vector<PendingEv> pending;
@@ -421,6 +428,9 @@ int dvo_create(int device, int max_w, int max_h, int max_levels, int n_slots, in
     CREATE_TRY(hipEventCreate(&ctx->tm_b));
     CREATE_TRY(hipEventCreateWithFlags(&ctx->ev_staging, hipEventDisableTiming));
     CREATE_TRY(hipEventCreateWithFlags(&ctx->ev_order, hipEventDisableTiming));
+    CREATE_TRY(hipEventCreateWithFlags(&ctx->ev_uploaded, hipEventDisableTiming));
+    CREATE_TRY(hipEventCreateWithFlags(&ctx->ev_ingested, hipEventDisableTiming));
+    CREATE_TRY(hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
     CREATE_TRY(hipStreamSynchronize(ctx->stream));
     {
         const char* e = getenv("DVO_GRAPH");
@@ -443,6 +453,10 @@ void dvo_destroy(dvo_ctx* ctx)
     if (ctx->tm_b) (void)hipEventDestroy(ctx->tm_b);
     if (ctx->ev_staging) (void)hipEventDestroy(ctx->ev_staging);
     if (ctx->ev_order) (void)hipEventDestroy(ctx->ev_order);
+    if (ctx->copy_stream) (void)hipStreamSynchronize(ctx->copy_stream);
+    if (ctx->ev_uploaded) (void)hipEventDestroy(ctx->ev_uploaded);
+    if (ctx->ev_ingested) (void)hipEventDestroy(ctx->ev_ingested);
+    if (ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);
     void* dev[] = {ctx->d_slots, ctx->d_prev, ctx->d_cur, ctx->d_T, ctx->d_Tinit, ctx->d_wparam, ctx->d_active, ctx->d_partials,
                    ctx->d_out, ctx->d_state, ctx->d_xi, ctx->d_iters, ctx->d_err, ctx->d_stage_img, ctx->d_dense, ctx->d_trace, ctx->d_frame_slots, ctx->d_prior, ctx->d_batch_stage,
                    ctx->d_list_count, ctx->d_seg_counts};
@@ -582,9 +596,37 @@ int dvo_upload_frames(dvo_ctx* ctx, int n_frames, const int* slots, const uint8_
     }
     uint8_t* sg = ctx->d_batch_stage;
     uint16_t* sd = reinterpret_cast<uint16_t*>(ctx->d_batch_stage + align_up(npx * n_frames, 256));
-    HIP_TRY(ctx, hipMemcpyAsync(sg, gray, npx * n_frames, hipMemcpyHostToDevice, ctx->stream));
-    HIP_TRY(ctx, hipMemcpyAsync(sd, depth, npx * n_frames * 2, hipMemcpyHostToDevice, ctx->stream));
-    return dvo_upload_frames_device(ctx, n_frames, slots, sg, sd, w, h, levels);
+    if (ctx->upload_peer == nullptr) {
+        HIP_TRY(ctx, hipMemcpyAsync(sg, gray, npx * n_frames, hipMemcpyHostToDevice, ctx->stream));
+        HIP_TRY(ctx, hipMemcpyAsync(sd, depth, npx * n_frames * 2, hipMemcpyHostToDevice, ctx->stream));
+        return dvo_upload_frames_device(ctx, n_frames, slots, sg, sd, w, h, levels);
+    }
+    // Copies on the shared in-order copy stream (uploads of different contexts take turns on the link without any
+    // cross-stream wait in front of a copy: the runtime may resolve such a wait on the host, blocking the caller);
+    // only kernels wait, by event.  The staging area is reused: the copy waits for the ingest kernels of the previous
+    // upload of this ctx, an event that completed long ago in steady state.
+    hipStream_t cs = ctx->upload_peer->copy_stream;
+    if (ctx->ingested_recorded) HIP_TRY(ctx, hipStreamWaitEvent(cs, ctx->ev_ingested, 0));
+    HIP_TRY(ctx, hipMemcpyAsync(sg, gray, npx * n_frames, hipMemcpyHostToDevice, cs));
+    HIP_TRY(ctx, hipMemcpyAsync(sd, depth, npx * n_frames * 2, hipMemcpyHostToDevice, cs));
+    HIP_TRY(ctx, hipEventRecord(ctx->ev_uploaded, cs));
+    HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_uploaded, 0));
+    int rc = dvo_upload_frames_device(ctx, n_frames, slots, sg, sd, w, h, levels);
+    if (rc) return rc;
+    HIP_TRY(ctx, hipEventRecord(ctx->ev_ingested, ctx->stream));
+    ctx->ingested_recorded = true;
+    return DVO_OK;
+}
+
+int dvo_set_upload_peer(dvo_ctx* ctx, dvo_ctx* peer)
+{
+    if (!ctx) return DVO_ERR_INVALID_ARG;
+    if (peer && peer->device != ctx->device) return fail(ctx, DVO_ERR_INVALID_ARG, "dvo_set_upload_peer: contexts are on different devices");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->upload_peer) HIP_TRY(ctx, hipStreamSynchronize(ctx->upload_peer->copy_stream));
+    ctx->upload_peer = peer;
+    return DVO_OK;
 }
 
 int dvo_wait_for(dvo_ctx* ctx, dvo_ctx* other)

@@ -47,6 +47,7 @@ SIGNATURES = {
     "dvo_upload_frames_device": (C.c_int, [_ctx, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int]),
     "dvo_upload_frames": (C.c_int, [_ctx, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int]),
     "dvo_wait_for": (C.c_int, [_ctx, _ctx]),
+    "dvo_set_upload_peer": (C.c_int, [_ctx, _ctx]),
     "dvo_host_alloc": (C.c_int, [C.c_size_t, C.POINTER(C.c_void_p)]),
     "dvo_host_free": (C.c_int, [C.c_void_p]),
     "dvo_upload_frame_bgr": (C.c_int, [_ctx, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_double]),
@@ -172,6 +173,10 @@ class HipContext:
     def wait_for(self, other: "HipContext"):
         """Work enqueued on this ctx from now on waits (on the GPU) for everything enqueued on `other` so far."""
         self._check(self._lib.dvo_wait_for(self._h, other._h))
+
+    def set_upload_peer(self, peer: Optional["HipContext"]):
+        """Host->device copies of `upload_frames` go to `peer`'s in-order copy stream (None: back to this ctx's stream)."""
+        self._check(self._lib.dvo_set_upload_peer(self._h, peer._h if peer is not None else None))
 
     # -- camera -----------------------------------------------------------------------------------
     def set_camera(self, fx, fy, cx, cy, skew, depth_scale):

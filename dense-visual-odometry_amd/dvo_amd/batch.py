@@ -96,9 +96,11 @@ class StreamedAligner:
         self.parts = [BatchAligner(K, depth_scale, width, height, levels, max_pairs=per, device=device, **kw)
                       for _ in range(n_streams)]
         self.ctx = self.parts[0].ctx
+        for a in self.parts:                       # host uploads of all slices take turns on one in-order copy stream
+            a.ctx.set_upload_peer(self.ctx)
 
     def close(self):
-        for a in self.parts:
+        for a in reversed(self.parts):             # parts[0] owns the shared copy stream: closed last
             a.close()
 
     def _slices(self, n_frames):
@@ -124,13 +126,8 @@ class StreamedAligner:
         """Host frames [n][h][w] (ideally page-locked): the H2D copy of one slice overlaps the solve of another."""
         n_frames = gray.shape[0]
         sl = self._slices(n_frames)
-        prev = None
-        for a, lo, hi in sl:
-            if prev is not None:
-                a.ctx.wait_for(prev.ctx)        # uploads take turns on the PCIe link; each solve starts behind its own
-            a.ingest_host(gray[lo:hi + 1], depth[lo:hi + 1])
-            prev = a
-        for a, lo, hi in sl:
+        for a, lo, hi in sl:                    # copies queue up on the shared copy stream in this order; the kernels
+            a.ingest_host(gray[lo:hi + 1], depth[lo:hi + 1])      # of a slice start behind its own copies only
             a.solve_enqueue(hi - lo + 1)
         res = [a.solve_fetch(hi - lo + 1) for a, lo, hi in sl]
         return {k: np.concatenate([r[k] for r in res], axis=0) for k in res[0]}

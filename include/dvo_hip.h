@@ -119,6 +119,12 @@ int dvo_upload_frames(dvo_ctx* ctx, int n_frames, const int* slots, const uint8_
  * everything enqueued on `other` so far has finished (event record + stream wait; nothing blocks on the host).
  * Used to run the uploads of several contexts one after another on the PCIe link while their solves overlap. */
 int dvo_wait_for(dvo_ctx* ctx, dvo_ctx* other);
+/* Several contexts of one GPU fed from host memory: after this call the host->device copies of dvo_upload_frames(ctx)
+ * are issued on `peer`'s copy stream (peer may be ctx itself; NULL restores copies on the ctx stream) and the ctx
+ * stream waits for them by event.  With one peer for all contexts the uploads take turns on the PCIe link in call
+ * order while each context's kernels run behind its own copies only: upload of one overlaps the solve of another.
+ * `peer` must outlive `ctx`'s last upload. */
+int dvo_set_upload_peer(dvo_ctx* ctx, dvo_ctx* peer);
 /* Page-locked host memory for the upload paths (hipHostMalloc / hipHostFree). */
 int dvo_host_alloc(size_t bytes, void** out);
 int dvo_host_free(void* p);

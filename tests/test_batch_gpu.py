@@ -98,11 +98,21 @@ def test_batched_host_upload_and_streamed_aligner(vga_stream):
     ref = BatchAligner(st["K"], st["depth_scale"], 640, 480, 4, max_pairs=8, max_iterations=10)
     r0 = ref.align_host(st["gray"], st["depth"])
     lvl2 = ref.ctx.download_level(3, 2)
-    ref.close()
+    r0_rev = ref.align_host(st["gray"][::-1], st["depth"][::-1])
     sa = StreamedAligner(st["K"], st["depth_scale"], 640, 480, 4, max_pairs=8, n_streams=2, max_iterations=10)
     r1 = sa.align_host(g, d)
     got = sa.parts[0].ctx.download_level(3, 2)
+    # back-to-back uploads through the shared copy stream reuse each slice's staging area: the second batch (frames in
+    # reverse order) must not overtake the ingest kernels of the first
+    g2 = _cabi.pinned_array(st["gray"].shape, np.uint8)
+    d2 = _cabi.pinned_array(st["depth"].shape, np.uint16)
+    g2[...] = st["gray"][::-1]
+    d2[...] = st["depth"][::-1]
+    sa.align_host(g, d)
+    r2 = sa.align_host(g2, d2)
     sa.close()
+    ref.close()
+    np.testing.assert_allclose(r2["xi"], r0_rev["xi"], rtol=0, atol=1e-9)
     for k in ("gray", "depth", "gx", "gy"):
         assert np.array_equal(got[k], lvl2[k])
     assert r1["xi"].shape == (8, 6)
