@@ -61,7 +61,10 @@ struct dvo_ctx {
     double* d_wparam = nullptr;
     int* d_active = nullptr;
     int* d_frame_slots = nullptr;
-    int* h_frame_slots = nullptr;
+    int* h_frame_slots = nullptr;        // page-locked ring of DVO_FS_RING slot-id lists: an asynchronous upload reads its list later
+    hipEvent_t ev_fs[4] = {nullptr, nullptr, nullptr, nullptr};
+    bool fs_used[4] = {false, false, false, false};
+    int fs_next = 0;
     int* d_list_count = nullptr;         // [n_slots][DVO_LIST_LEVELS] records in each slot's valid-point lists
     int* d_seg_counts = nullptr;         // list-builder scratch [n_slots][segments of all levels]
     int segs_per_frame = 0;
@@ -308,6 +311,21 @@ int fill_reduce_params(dvo_ctx* ctx, int level, int n_pairs, int w, int h, DvoRe
     return DVO_OK;
 }
 
+// Slot ids of an upload go to the device with an asynchronous copy from a page-locked list; the lists form a ring so
+// that a following upload on the same ctx does not overwrite one the copy engine has not read yet.
+int stage_frame_slots(dvo_ctx* ctx, const int* slots, int n)
+{
+    const int k = ctx->fs_next;
+    ctx->fs_next = (k + 1) & 3;
+    if (ctx->fs_used[k]) HIP_TRY(ctx, hipEventSynchronize(ctx->ev_fs[k]));
+    int* hbuf = ctx->h_frame_slots + (size_t)k * ctx->n_slots;
+    memcpy(hbuf, slots, (size_t)n * sizeof(int));
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->d_frame_slots, hbuf, (size_t)n * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipEventRecord(ctx->ev_fs[k], ctx->stream));
+    ctx->fs_used[k] = true;
+    return DVO_OK;
+}
+
 int build_pyramid_on_device(dvo_ctx* ctx, int slot, int w, int h, int levels)
 {
     // level 0 is already in the slot; the batched ingest kernels build the rest (n_frames = 1)
@@ -323,8 +341,8 @@ int build_pyramid_on_device(dvo_ctx* ctx, int slot, int w, int h, int levels)
     p.list_count = ctx->d_list_count;
     p.seg_counts = ctx->d_seg_counts;
     level_geometry(w, h, levels, p.g, nullptr);
-    ctx->h_frame_slots[0] = slot;
-    HIP_TRY(ctx, hipMemcpyAsync(ctx->d_frame_slots, ctx->h_frame_slots, sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+    int rc = stage_frame_slots(ctx, &slot, 1);
+    if (rc) return rc;
     HIP_TRY(ctx, dvo_launch_batch_ingest(p, ctx->stream));
     return DVO_OK;
 }
@@ -400,7 +418,8 @@ int dvo_create(int device, int max_w, int max_h, int max_levels, int n_slots, in
     CREATE_TRY(hipMalloc((void**)&ctx->d_wparam, np * sizeof(double)));
     CREATE_TRY(hipMalloc((void**)&ctx->d_active, np * sizeof(int)));
     CREATE_TRY(hipMalloc((void**)&ctx->d_frame_slots, (size_t)n_slots * sizeof(int)));
-    CREATE_TRY(hipHostMalloc((void**)&ctx->h_frame_slots, (size_t)n_slots * sizeof(int)));
+    CREATE_TRY(hipHostMalloc((void**)&ctx->h_frame_slots, 4 * (size_t)n_slots * sizeof(int)));
+    for (int i = 0; i < 4; ++i) CREATE_TRY(hipEventCreateWithFlags(&ctx->ev_fs[i], hipEventDisableTiming));
     for (int l = 0; l < lv; ++l) ctx->segs_per_frame += g[l].nseg;
     CREATE_TRY(hipMalloc((void**)&ctx->d_list_count, (size_t)n_slots * DVO_LIST_LEVELS * sizeof(int)));
     CREATE_TRY(hipMemsetAsync(ctx->d_list_count, 0, (size_t)n_slots * DVO_LIST_LEVELS * sizeof(int), ctx->stream));
@@ -453,6 +472,7 @@ void dvo_destroy(dvo_ctx* ctx)
     if (ctx->tm_b) (void)hipEventDestroy(ctx->tm_b);
     if (ctx->ev_staging) (void)hipEventDestroy(ctx->ev_staging);
     if (ctx->ev_order) (void)hipEventDestroy(ctx->ev_order);
+    for (int i = 0; i < 4; ++i) if (ctx->ev_fs[i]) (void)hipEventDestroy(ctx->ev_fs[i]);
     if (ctx->copy_stream) (void)hipStreamSynchronize(ctx->copy_stream);
     if (ctx->ev_uploaded) (void)hipEventDestroy(ctx->ev_uploaded);
     if (ctx->ev_ingested) (void)hipEventDestroy(ctx->ev_ingested);
@@ -569,8 +589,10 @@ int dvo_upload_frames_device(dvo_ctx* ctx, int n_frames, const int* slots, const
     p.list_count = ctx->d_list_count;
     p.seg_counts = ctx->d_seg_counts;
     level_geometry(w, h, levels, p.g, nullptr);
-    memcpy(ctx->h_frame_slots, slots, (size_t)n_frames * sizeof(int));
-    HIP_TRY(ctx, hipMemcpyAsync(ctx->d_frame_slots, ctx->h_frame_slots, (size_t)n_frames * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+    {
+        int rc = stage_frame_slots(ctx, slots, n_frames);
+        if (rc) return rc;
+    }
     HIP_TRY(ctx, dvo_launch_batch_ingest(p, ctx->stream));
     for (int i = 0; i < n_frames; ++i) ctx->slots[slots[i]].ready = true;
     return DVO_OK;

@@ -59,6 +59,30 @@ def test_device_ingest_equals_host_ingest(vga_stream):
     assert np.array_equal(res_dev["xi"], res_host["xi"])            # same data, deterministic reduction
 
 
+def test_back_to_back_asynchronous_uploads_on_one_context(vga_stream):
+    """Several dvo_upload_frames_device calls enqueued without a sync in between (different slot lists, different
+    frames): each call's slot-id list is read by the GPU later, from its own page-locked ring entry."""
+    import torch
+    import dvo_amd
+    st = vga_stream
+    g = torch.from_numpy(st["gray"]).cuda()
+    d = torch.from_numpy(st["depth"].view(np.int16)).cuda()
+    npx = 640 * 480
+    with dvo_amd.HipContext(max_w=640, max_h=480, max_levels=3, n_slots=9, max_pairs=1) as ctx:
+        K = st["K"]
+        ctx.set_camera(K[0, 0], K[1, 1], K[0, 2], K[1, 2], K[0, 1], st["depth_scale"])
+        order = [(np.array([7, 2], dtype=np.int32), 0), (np.array([0], dtype=np.int32), 2), (np.array([5, 1, 8], dtype=np.int32), 3),
+                 (np.array([3, 4], dtype=np.int32), 6), (np.array([6], dtype=np.int32), 8), (np.array([7], dtype=np.int32), 4)]
+        for slots, first in order:                                   # six uploads, nothing waits in between
+            ctx.upload_frames_device(slots, g.data_ptr() + first * npx, d.data_ptr() + 2 * first * npx, 640, 480, 3)
+        ctx.synchronize()
+        expect = {2: 1, 0: 2, 5: 3, 1: 4, 8: 5, 3: 6, 4: 7, 6: 8, 7: 4}     # slot -> frame (slot 7 overwritten last)
+        for slot, frame in expect.items():
+            got = ctx.download_level(slot, 2, want=("gray", "depth"))
+            assert np.array_equal(got["gray"], O.build_pyramid(st["gray"][frame], 3)[2]), (slot, frame)
+            assert np.array_equal(got["depth"], O.build_pyramid(st["depth"][frame], 3)[2]), (slot, frame)
+
+
 def test_huber_and_student_t_device_vs_oracle(vga_stream):
     from dvo_amd.batch import BatchAligner
     st = vga_stream
