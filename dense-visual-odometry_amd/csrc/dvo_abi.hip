@@ -78,6 +78,7 @@ struct dvo_ctx {
     uint8_t* d_stage_img = nullptr;      // staging for host->device image uploads (bgr needs 3 B/px + depth)
     uint8_t* d_batch_stage = nullptr;    // staging of dvo_upload_frames (whole batches), grown on demand
     size_t batch_stage_bytes = 0;
+    float* d_rcache = nullptr;           // Student-t device solve: residuals kept between the scale passes [max_pairs][max_w*max_h]
     float* d_dense = nullptr;            // dense writer outputs: r[npix] J[6 npix] uv[2 npix] + valid
     double* d_trace = nullptr;
     int trace_cap = 0;
@@ -285,6 +286,7 @@ int fill_reduce_params(dvo_ctx* ctx, int level, int n_pairs, int w, int h, DvoRe
     p->partials = ctx->d_partials;
     p->list_count = ctx->d_list_count;
     p->level = level;
+    p->rcache = nullptr;
     {
         const char* e = getenv("DVO_XCD_REMAP");
         p->xcd_remap = (e && e[0] == '1') ? 1 : 0;   // measured slower on MI355X, off by default
@@ -479,7 +481,7 @@ void dvo_destroy(dvo_ctx* ctx)
     if (ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);
     void* dev[] = {ctx->d_slots, ctx->d_prev, ctx->d_cur, ctx->d_T, ctx->d_Tinit, ctx->d_wparam, ctx->d_active, ctx->d_partials,
                    ctx->d_out, ctx->d_state, ctx->d_xi, ctx->d_iters, ctx->d_err, ctx->d_stage_img, ctx->d_dense, ctx->d_trace, ctx->d_frame_slots, ctx->d_prior, ctx->d_batch_stage,
-                   ctx->d_list_count, ctx->d_seg_counts};
+                   ctx->d_list_count, ctx->d_seg_counts, ctx->d_rcache};
     for (void* p : dev) if (p) (void)hipFree(p);
     void* host[] = {ctx->hs.prev, ctx->hs.cur, ctx->hs.T, ctx->hs.wparam, ctx->hs.out, ctx->hs.xi, ctx->hs.iters, ctx->hs.err, ctx->h_frame_slots, ctx->h_prior};
     for (void* p : host) if (p) (void)hipHostFree(p);
@@ -895,11 +897,15 @@ static int record_solve(dvo_ctx* ctx, const SolveKey& k, const float* d_init)
         for (int it = 0; it < max_iterations; ++it) {
             if (weight_mode == DVO_WEIGHT_STUDENT_T) {
                 // the two IRLS scale passes the reference's loop takes (weighter/t_weighter.py:24-32)
+                // (the first pass keeps the residuals of this pose; the second sums them again under the new lambda)
+                p.rcache = ctx->d_rcache;
                 for (int pass = 1; pass <= 2; ++pass) {
-                    HIP_TRY(ctx, launch_reduce_profiled(ctx, p, level, variant, 1, 1));
+                    if (pass == 1 || ctx->d_rcache == nullptr) HIP_TRY(ctx, launch_reduce_profiled(ctx, p, level, variant, 1, 1));
+                    else HIP_TRY(ctx, dvo_launch_scale_cached(p, ctx->stream));
                     sp.phase = pass;
                     HIP_TRY(ctx, dvo_launch_solve(sp, ctx->stream));
                 }
+                p.rcache = nullptr;
             }
             HIP_TRY(ctx, launch_reduce_profiled(ctx, p, level, variant, weight_mode, 0));
             sp.phase = 0;
@@ -926,6 +932,14 @@ int dvo_solve_batch_enqueue(dvo_ctx* ctx, int n_pairs, const int* prev_slot, con
     if (rc) return rc;
     rc = stage_pairs(ctx, n_pairs, prev_slot, cur_slot, nullptr, nullptr);
     if (rc) return rc;
+    if (weight_mode == DVO_WEIGHT_STUDENT_T && ctx->d_rcache == nullptr && getenv("DVO_NO_RCACHE") == nullptr) {
+        // residual cache of the scale passes (allocated on first use, outside any graph capture); without it the second
+        // pass recomputes the residuals
+        if (hipMalloc((void**)&ctx->d_rcache, (size_t)ctx->max_pairs * ctx->max_w * ctx->max_h * sizeof(float)) != hipSuccess) {
+            (void)hipGetLastError();
+            ctx->d_rcache = nullptr;
+        }
+    }
     const float* d_init = nullptr;
     if (T_init) {
         memcpy(ctx->hs.T, T_init, (size_t)n_pairs * 12 * sizeof(float));

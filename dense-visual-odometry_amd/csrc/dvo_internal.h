@@ -62,6 +62,8 @@ struct DvoReduceParams {
     int n_pairs;
     const int* list_count;      // [n_slots][DVO_LIST_LEVELS] number of records in each slot's list
     int level;
+    float* rcache;              // Student-t scale passes: [n_pairs][g.npix] residual of every record of the current pose
+                                // (NaN: out of bounds), written by the first pass and read by the second; or null
 };
 
 struct DvoDenseParams {
@@ -130,6 +132,7 @@ hipError_t dvo_launch_bgr_ingest(const uint8_t* bgr, const uint16_t* depth_in, i
 hipError_t dvo_launch_batch_ingest(const DvoBatchIngestParams& p, hipStream_t s);
 hipError_t dvo_launch_unpack(const uint32_t* packed, int w, int h, int pitch, int16_t* gx, int16_t* gy, hipStream_t s);
 hipError_t dvo_launch_reduce(const DvoReduceParams& p, int variant, int weight_mode, int scale_pass, hipStream_t s);
+hipError_t dvo_launch_scale_cached(const DvoReduceParams& p, hipStream_t s);
 hipError_t dvo_launch_sum_partials(const double* partials, int blocks_per_pair, int n_pairs, double* out, hipStream_t s);
 hipError_t dvo_launch_dense(const DvoDenseParams& p, int variant, hipStream_t s);
 hipError_t dvo_launch_init_state(DvoPairState* st, float* T, const float* T_init, int n_pairs, double lambda0,

@@ -897,6 +897,11 @@ __global__ __launch_bounds__(DVO_BLOCK, (VARIANT == 2) ? 2 : DVO_REDUCE_WAVES_PE
             dvo_load_taps(p.g, packed_cur, geo[j], taps[j]);
             if (VARIANT == 1) taps[j].own = geo[j].ok ? packed_prev[yi * (unsigned)p.g.pitch + xi] : 0u;
         }
+        float rkeep[SCALE_PASS ? DVO_PX_PER_THREAD : 1];
+        if constexpr (SCALE_PASS) {
+#pragma unroll
+            for (int j = 0; j < DVO_PX_PER_THREAD; ++j) rkeep[j] = __builtin_nanf("");
+        }
 #pragma unroll
         for (int j = 0; j < DVO_PX_PER_THREAD; ++j) {
             if (geo[j].ok) {                                  // depth != 0 (camera_model.py:195) and in bounds
@@ -911,6 +916,7 @@ __global__ __launch_bounds__(DVO_BLOCK, (VARIANT == 2) ? 2 : DVO_REDUCE_WAVES_PE
                 if constexpr (SCALE_PASS) {
                     // r^2 * (dof+1)/(dof + r^2*lambda), dof = 5 (weighter/t_weighter.py:43-45)
                     acc[0] += r2 * (6.0f * fast_rcp(fmaf(r2, wpar, 5.0f)));
+                    rkeep[j] = r;
                 } else {
                     float wt = 1.0f;
                     if (WMODE == 1) wt = 6.0f * fast_rcp(fmaf(r2, wpar, 5.0f));              // t_weighter.py:34
@@ -929,6 +935,15 @@ __global__ __launch_bounds__(DVO_BLOCK, (VARIANT == 2) ? 2 : DVO_REDUCE_WAVES_PE
                     acc[28] += 1.0f;
                     if (WMODE != 0) acc[29] += r2;             // WMODE 0: copied from acc[27] after the loop
                 }
+            }
+        }
+        if constexpr (SCALE_PASS) {
+            // the residuals do not change between the scale passes of one pose: keep them for the next pass
+            if (p.rcache != nullptr) {
+                float* rc_out = p.rcache + (size_t)pair * p.g.npix + seg + lane_;
+#pragma unroll
+                for (int j = 0; j < DVO_PX_PER_THREAD; ++j)
+                    if (seg + j * 64 + lane_ < count) rc_out[j * 64] = rkeep[j];
             }
         }
     }
@@ -953,6 +968,55 @@ __global__ __launch_bounds__(DVO_BLOCK, (VARIANT == 2) ? 2 : DVO_REDUCE_WAVES_PE
         double* out = p.partials + ((size_t)pair * p.blocks_per_pair + blk) * DVO_STRIDE;
         block_reduce_terms(acc, out);
     }
+}
+
+// Second (and any later) Student-t scale pass of one pose: the same sum as k_reduce<..., SCALE_PASS> over the residuals
+// the first pass kept, with the same record->lane map, the same per-lane order and the same cross-lane combination, so
+// the result is bit-identical to recomputing the residuals.
+__global__ __launch_bounds__(DVO_BLOCK) void k_scale_cached(const DvoReduceParams p)
+{
+    const int lb = blockIdx.x;
+    const int pair = lb / p.blocks_per_pair;
+    const int blk = lb - pair * p.blocks_per_pair;
+    if (p.active != nullptr && p.active[pair] == 0) return;
+    const int lane_ = threadIdx.x & 63, wave_ = threadIdx.x >> 6;
+    const int count = p.list_count[p.prev_slot[pair] * DVO_LIST_LEVELS + p.level];
+    const int rec0 = (blk * p.groups_per_block * (DVO_BLOCK / 64) + wave_) * (64 * DVO_PX_PER_THREAD);
+    const float wpar = (float)p.wparam[pair];
+    const float* rc_in = p.rcache + (size_t)pair * p.g.npix;
+    float acc = 0.0f;
+    for (int grp = 0; grp < p.groups_per_block; ++grp) {
+        const int seg = rec0 + grp * (DVO_BLOCK / 64) * (64 * DVO_PX_PER_THREAD);
+        if (seg >= count) break;
+        float r[DVO_PX_PER_THREAD];
+#pragma unroll
+        for (int j = 0; j < DVO_PX_PER_THREAD; ++j) {
+            const int idx = seg + j * 64 + lane_;
+            r[j] = (idx < count) ? rc_in[idx] : __builtin_nanf("");
+        }
+#pragma unroll
+        for (int j = 0; j < DVO_PX_PER_THREAD; ++j) {
+            if (r[j] == r[j]) {
+                const float r2 = r[j] * r[j];
+                acc += r2 * (6.0f * fast_rcp(fmaf(r2, wpar, 5.0f)));
+            }
+        }
+    }
+    __shared__ double lds1[DVO_BLOCK / 64];
+    const double sw = wave_sum((double)acc);
+    if ((threadIdx.x & 63) == 0) lds1[threadIdx.x >> 6] = sw;
+    __syncthreads();
+    if (threadIdx.x < DVO_STRIDE) {
+        double tot = 0.0;
+        if (threadIdx.x == 0) tot = (lds1[0] + lds1[1]) + (lds1[2] + lds1[3]);
+        p.partials[((size_t)pair * p.blocks_per_pair + blk) * DVO_STRIDE + threadIdx.x] = tot;
+    }
+}
+
+hipError_t dvo_launch_scale_cached(const DvoReduceParams& p, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_scale_cached, dim3((unsigned)(p.n_pairs * p.blocks_per_pair)), dim3(DVO_BLOCK), 0, s, p);
+    return hipGetLastError();
 }
 
 template <int VARIANT, int TAG, bool SKEW>

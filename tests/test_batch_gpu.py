@@ -96,6 +96,24 @@ def test_huber_and_student_t_device_vs_oracle(vga_stream):
             np.testing.assert_allclose(res["xi"][k], est.log(), rtol=0, atol=2e-6)
 
 
+def test_student_t_residual_cache_is_bit_identical_to_recomputation(vga_stream, monkeypatch):
+    """The second Student-t scale pass of an iteration sums the residuals the first pass kept; DVO_NO_RCACHE makes it
+    recompute them (the pre-cache behaviour).  Same record->lane map and summation order => identical poses."""
+    from dvo_amd.batch import BatchAligner
+    st = vga_stream
+    out = []
+    for no_cache in (False, True):
+        if no_cache:
+            monkeypatch.setenv("DVO_NO_RCACHE", "1")
+        else:
+            monkeypatch.delenv("DVO_NO_RCACHE", raising=False)
+        al = BatchAligner(st["K"], st["depth_scale"], 640, 480, 4, max_pairs=8, max_iterations=6,
+                          weighting="student_t_reference")
+        out.append(al.align_host(st["gray"], st["depth"]))
+        al.close()
+    assert np.array_equal(out[0]["xi"], out[1]["xi"]) and np.array_equal(out[0]["err"], out[1]["err"])
+
+
 def test_config3_1280x960_five_levels_huber():
     """BASELINE config 3 shape: 1280x960, 5-level pyramid, Huber weighting — converges to the rendered motion."""
     from dvo_amd import synthetic
