@@ -854,7 +854,11 @@ __global__ __launch_bounds__(DVO_BLOCK, (VARIANT == 2) ? 2 : DVO_REDUCE_WAVES_PE
     const int lane_ = threadIdx.x & 63, wave_ = threadIdx.x >> 6;
     const DvoPointRec* list = reinterpret_cast<const DvoPointRec*>(prev + p.g.off_list);
     const int count = p.list_count[p.prev_slot[pair] * DVO_LIST_LEVELS + p.level];
-    const int rec0 = (blk * p.groups_per_block * (DVO_BLOCK / 64) + wave_) * (64 * DVO_PX_PER_THREAD);   // wave-uniform
+    // Groups of 1024 records are dealt round-robin to the workgroups of the pair (group g -> workgroup g mod n): the list is
+    // shorter than the pixel count the grid was sized for, and this way every workgroup gets the same share of it whatever
+    // its length (a contiguous split leaves the last workgroups of every pair empty and the launch unbalanced).
+    const int gstride = p.blocks_per_pair * (DVO_BLOCK / 64) * (64 * DVO_PX_PER_THREAD);
+    const int rec0 = (blk * (DVO_BLOCK / 64) + wave_) * (64 * DVO_PX_PER_THREAD);   // wave-uniform
     // the records of the next group are requested one group ahead, so their latency is covered by the arithmetic of
     // the current group and only the dependent tap gathers are waited for
     uint2 rn[DVO_PX_PER_THREAD];
@@ -865,13 +869,13 @@ __global__ __launch_bounds__(DVO_BLOCK, (VARIANT == 2) ? 2 : DVO_REDUCE_WAVES_PE
         for (int j = 0; j < DVO_PX_PER_THREAD; ++j) rn[j] = *reinterpret_cast<const uint2*>(list + rec0 + j * 64 + lane_);
     }
     for (int grp = 0; grp < p.groups_per_block; ++grp) {
-        const int seg = rec0 + grp * (DVO_BLOCK / 64) * (64 * DVO_PX_PER_THREAD);
+        const int seg = rec0 + grp * gstride;
         if (seg >= count) break;                                          // wave-uniform
         uint2 rc[DVO_PX_PER_THREAD];
 #pragma unroll
         for (int j = 0; j < DVO_PX_PER_THREAD; ++j) rc[j] = rn[j];
         {
-            const int segn = seg + (DVO_BLOCK / 64) * (64 * DVO_PX_PER_THREAD);
+            const int segn = seg + gstride;
             if (grp + 1 < p.groups_per_block && segn < count) {           // (reads past `count` stay inside DVO_LIST_SLACK)
 #pragma unroll
                 for (int j = 0; j < DVO_PX_PER_THREAD; ++j) rn[j] = *reinterpret_cast<const uint2*>(list + segn + j * 64 + lane_);
@@ -981,12 +985,13 @@ __global__ __launch_bounds__(DVO_BLOCK) void k_scale_cached(const DvoReduceParam
     if (p.active != nullptr && p.active[pair] == 0) return;
     const int lane_ = threadIdx.x & 63, wave_ = threadIdx.x >> 6;
     const int count = p.list_count[p.prev_slot[pair] * DVO_LIST_LEVELS + p.level];
-    const int rec0 = (blk * p.groups_per_block * (DVO_BLOCK / 64) + wave_) * (64 * DVO_PX_PER_THREAD);
+    const int gstride = p.blocks_per_pair * (DVO_BLOCK / 64) * (64 * DVO_PX_PER_THREAD);
+    const int rec0 = (blk * (DVO_BLOCK / 64) + wave_) * (64 * DVO_PX_PER_THREAD);
     const float wpar = (float)p.wparam[pair];
     const float* rc_in = p.rcache + (size_t)pair * p.g.npix;
     float acc = 0.0f;
     for (int grp = 0; grp < p.groups_per_block; ++grp) {
-        const int seg = rec0 + grp * (DVO_BLOCK / 64) * (64 * DVO_PX_PER_THREAD);
+        const int seg = rec0 + grp * gstride;
         if (seg >= count) break;
         float r[DVO_PX_PER_THREAD];
 #pragma unroll
