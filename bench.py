@@ -58,7 +58,7 @@ def parse_args():
     ap.add_argument("--streams", type=int, default=4, help="independent HIP streams (sub-batches) per GPU")
     ap.add_argument("--distinct", type=int, default=0, help="distinct rendered frames (0 = batch+1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-pairs", type=int, default=8)
+    ap.add_argument("--cpu-pairs", type=int, default=32, help="frame pairs of the CPU baseline sample (~0.35 s each)")
     return ap.parse_args()
 
 
@@ -210,7 +210,7 @@ def main():
             "dtype_note": "float32 per-pixel arithmetic (as the reference), float64 accumulation and 6x6 solve",
             "data": "synthetic",
             "config": {"workload": "synthetic %dx%d RGB-D stream, %d-level pyramid, %d GN iterations/level, "
-                                   "%d frame pairs per GPU per step (pyramid+Sobel build and device-side GN solve "
+                                   "%d frame pairs per GPU per step (pyramid + Sobel + valid-point-list build and device-side GN solve "
                                    "inside the timed region), weighting=%s" % (W, H, L, args.iterations, B, args.weighting),
                        "batch_pairs_per_gpu": B, "streams_per_gpu": args.streams, "distinct_frames": int(min(n_distinct, n_frames)),
                        "gn_iterations_per_pair": iters_total / B,
