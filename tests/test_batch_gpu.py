@@ -174,3 +174,24 @@ def test_rccl_pose_gather_through_the_c_abi():
     out = comm.allgather(rec[:2] * 3)
     assert np.array_equal(out, rec[:2] * 3)
     comm.close()
+
+
+def test_contexts_release_their_device_memory(vga_stream):
+    """Create / use / destroy cycles (incl. the lazily allocated Student-t cache, batch staging, graphs, peer copy stream)
+    leave the free device memory where it was."""
+    import torch
+    from dvo_amd.batch import StreamedAligner
+    st = vga_stream
+    torch.cuda.synchronize()
+    free0 = None
+    for cycle in range(6):
+        sa = StreamedAligner(st["K"], st["depth_scale"], 640, 480, 4, max_pairs=8, n_streams=2, max_iterations=3,
+                             weighting="student_t_reference" if cycle % 2 else "none")
+        sa.align_host(st["gray"], st["depth"])
+        sa.close()
+        torch.cuda.synchronize()
+        free = torch.cuda.mem_get_info()[0]
+        if cycle == 1:
+            free0 = free                              # after the first cycles: runtime pools are warm
+        if cycle > 1:
+            assert free >= free0 - (32 << 20), (cycle, free0 - free)
