@@ -64,6 +64,7 @@ def parse_args():
 
 def cpu_baseline(stream_np, levels, iterations, n_pairs):
     """Oracle (NumPy port of the reference CPU path, float32 J^T J like the reference) on a bounded sample."""
+    import numpy as np
     sys.path.insert(0, str(ROOT / "oracle"))
     import dvo_oracle as O
     try:
@@ -82,9 +83,31 @@ def cpu_baseline(stream_np, levels, iterations, n_pairs):
     dt = time.perf_counter() - t0
     if limiter is not None:
         limiter.unregister() if hasattr(limiter, "unregister") else None
-    return {"value": n_pairs / dt, "unit": "frame-pairs/s", "cores": 1, "kind": "port",
-            "sample": "%d VGA frame pairs x %d levels x %d GN iterations, NumPy oracle (float32 J^T J), 1 thread, "
-                      "%.1f s; host has %d logical CPUs" % (n_pairs, levels, iterations, dt, os.cpu_count() or 0)}
+    out = {"value": n_pairs / dt, "unit": "frame-pairs/s", "cores": 1, "kind": "port",
+           "sample": "%d VGA frame pairs x %d levels x %d GN iterations, NumPy oracle (float32 J^T J), 1 thread, "
+                     "%.1f s; host has %d logical CPUs" % (n_pairs, levels, iterations, dt, os.cpu_count() or 0)}
+    # the same sample spread over worker processes (pairs are independent, as on the GPU): the host's throughput with the
+    # cores one GPU's share of the node has.  The workers are plain child processes running oracle/cpu_worker.py: they
+    # import NumPy and the oracle only, never torch / HIP.  Each reports the seconds of its own range (interpreter
+    # start-up and a warm-up pair excluded); they start together, so the slowest worker's time is the wall time.
+    try:
+        import subprocess
+        import tempfile
+        workers = max(1, min(16, os.cpu_count() or 1, n_pairs))
+        with tempfile.TemporaryDirectory() as tmp:
+            path = os.path.join(tmp, "cpu_sample.npz")
+            np.savez(path, gray=g[:n_pairs + 1], depth=d[:n_pairs + 1], K=stream_np["K"], depth_scale=stream_np["depth_scale"])
+            bounds = [round(i * n_pairs / workers) for i in range(workers + 1)]
+            env = dict(os.environ, OMP_NUM_THREADS="1", OPENBLAS_NUM_THREADS="1", MKL_NUM_THREADS="1")
+            procs = [subprocess.Popen([sys.executable, str(ROOT / "oracle" / "cpu_worker.py"), path, str(bounds[i]), str(bounds[i + 1]),
+                                       str(levels), str(iterations)], stdout=subprocess.PIPE, env=env, text=True) for i in range(workers)]
+            secs = [float(p.communicate(timeout=600)[0].strip().splitlines()[-1]) for p in procs]
+        dtp = max(secs)
+        out["all_workers"] = {"value": n_pairs / dtp, "unit": "frame-pairs/s", "cores": workers,
+                              "sample": "the same %d pairs over %d single-threaded worker processes, slowest worker %.1f s" % (n_pairs, workers, dtp)}
+    except Exception as e:                                            # pragma: no cover
+        out["all_workers"] = {"error": repr(e)}
+    return out
 
 
 def fixture_ate(device):
