@@ -11,6 +11,9 @@
 #include <new>
 #include <vector>
 
+static_assert(DVO_LIST_LEVELS == DVO_MAX_LEVELS, "the list-count table has one column per pyramid level");
+static_assert(DVO_STRIDE == DVO_NE_STRIDE, "normal-equation record stride of the boundary");
+
 namespace {
 
 thread_local char g_create_error[512] = "";
