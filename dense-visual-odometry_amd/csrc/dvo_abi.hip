@@ -744,6 +744,35 @@ int dvo_download_level(dvo_ctx* ctx, int slot, int level, uint8_t* gray, uint16_
     return DVO_OK;
 }
 
+int dvo_download_points(dvo_ctx* ctx, int slot, int level, float* z, uint32_t* pix, int capacity, int* count)
+{
+    if (!ctx) return DVO_ERR_INVALID_ARG;
+    if (!count || capacity < 0) return fail(ctx, DVO_ERR_INVALID_ARG, "dvo_download_points: null count / negative capacity");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    int rc = check_slot(ctx, slot, "dvo_download_points");
+    if (rc) return rc;
+    const SlotInfo& s = ctx->slots[slot];
+    if (!s.lists) return fail(ctx, DVO_ERR_BAD_STATE, "slot %d was uploaded before dvo_set_camera (or under another depth_scale): upload it again", slot);
+    if (level < 0 || level >= s.levels) return fail(ctx, DVO_ERR_INVALID_ARG, "level %d outside [0,%d)", level, s.levels);
+    DvoLevelGeom g[DVO_MAX_LEVELS];
+    level_geometry(s.w, s.h, s.levels, g, nullptr);
+    int n = 0;
+    HIP_TRY(ctx, hipMemcpyAsync(&n, ctx->d_list_count + (size_t)slot * DVO_LIST_LEVELS + level, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    *count = n;
+    const int m = n < capacity ? n : capacity;
+    if (m > 0 && (z || pix)) {
+        std::vector<DvoPointRec> host((size_t)m);
+        const uint8_t* base = ctx->d_slots + (size_t)slot * ctx->slot_stride;
+        HIP_TRY(ctx, hipMemcpy(host.data(), base + g[level].off_list, (size_t)m * sizeof(DvoPointRec), hipMemcpyDeviceToHost));
+        for (int i = 0; i < m; ++i) {
+            if (z) z[i] = host[i].z;
+            if (pix) pix[i] = host[i].pix;
+        }
+    }
+    return DVO_OK;
+}
+
 static int stage_pairs(dvo_ctx* ctx, int n_pairs, const int* prev_slot, const int* cur_slot, const float* T,
                        const double* wparam)
 {

@@ -53,6 +53,7 @@ SIGNATURES = {
     "dvo_upload_frame_bgr": (C.c_int, [_ctx, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_double]),
     "dvo_download_level": (C.c_int, [_ctx, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "dvo_slot_info": (C.c_int, [_ctx, C.c_int, _c_int_p, _c_int_p, _c_int_p]),
+    "dvo_download_points": (C.c_int, [_ctx, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, _c_int_p]),
     "dvo_normal_equations": (C.c_int, [_ctx, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
                                        C.c_void_p, C.c_void_p]),
     "dvo_weighted_r2_sum": (C.c_int, [_ctx, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
@@ -230,6 +231,16 @@ class HipContext:
         w, h, lv = C.c_int(), C.c_int(), C.c_int()
         self._check(self._lib.dvo_slot_info(self._h, slot, C.byref(w), C.byref(h), C.byref(lv)))
         return w.value, h.value, lv.value
+
+    def download_points(self, slot: int, level: int):
+        """Valid-point list of one level -> dict(x, y, intensity, z) in raster order (depth-valid pixels only)."""
+        n = C.c_int(0)
+        self._check(self._lib.dvo_download_points(self._h, slot, level, None, None, 0, C.byref(n)))
+        z = np.empty(n.value, dtype=np.float32)
+        pix = np.empty(n.value, dtype=np.uint32)
+        self._check(self._lib.dvo_download_points(self._h, slot, level, _ptr(z), _ptr(pix), n.value, C.byref(n)))
+        return {"x": (pix & 0xfff).astype(np.int32), "y": ((pix >> 12) & 0xfff).astype(np.int32),
+                "intensity": (pix >> 24).astype(np.uint8), "z": z}
 
     def download_level(self, slot: int, level: int, want=("gray", "depth", "gx", "gy")):
         w, h, lv = self.slot_info(slot)

@@ -135,6 +135,12 @@ int dvo_upload_frame_bgr(dvo_ctx* ctx, int slot, const uint8_t* bgr, const uint1
 /* Copies one level of a slot back to the host (any pointer may be NULL). gx/gy are the unpacked Sobel planes. */
 int dvo_download_level(dvo_ctx* ctx, int slot, int level, uint8_t* gray, uint16_t* depth, int16_t* gx, int16_t* gy);
 int dvo_slot_info(const dvo_ctx* ctx, int slot, int* w, int* h, int* levels);
+/* Copies the valid-point list of one level back to the host, for tests and hosts that want the reference's deprojection
+ * inputs: *count = number of depth-valid pixels (mask of camera_model.py:195), and for the first min(*count, capacity) of
+ * them, in raster order, z[i] = (float)((double)depth * depth_scale) (camera_model.py:200-201) and
+ * pix[i] = x | y << 12 | intensity << 24.  z / pix may be NULL.  DVO_ERR_BAD_STATE if the slot was uploaded before
+ * dvo_set_camera. */
+int dvo_download_points(dvo_ctx* ctx, int slot, int level, float* z, uint32_t* pix, int capacity, int* count);
 
 /* ---- the hot path ------------------------------------------------------------------------------ */
 

@@ -69,6 +69,22 @@ def test_device_pyramid_and_gradients_bit_exact(hip, frames, pyramids):
             assert np.array_equal(d["gy"].astype(np.float32), gy)
 
 
+def test_valid_point_lists_bit_exact(hip, frames, pyramids):
+    """The work items of every Gauss-Newton iteration: the depth-valid pixels (camera_model.py:195) of each level in
+    raster order with z = (float)((double)depth * depth_scale) (:200-201) and the pixel's intensity — index work, bit exact."""
+    ctx, _ = hip
+    for k in (0, 7):
+        gp, dp = pyramids(k)
+        for lvl in range(4):
+            got = ctx.download_points(k, lvl)
+            ys, xs = np.nonzero(dp[lvl])                                     # row-major == raster order
+            assert got["x"].shape[0] == ys.shape[0]
+            assert np.array_equal(got["x"], xs) and np.array_equal(got["y"], ys)
+            assert np.array_equal(got["intensity"], gp[lvl][ys, xs])
+            z = (dp[lvl][ys, xs].astype(np.float64) * frames["depth_scale"]).astype(np.float32)
+            assert np.array_equal(got["z"], z)
+
+
 def test_level_intrinsics_bit_exact(hip, frames):
     ctx, _ = hip
     for lvl in range(5):
@@ -584,8 +600,8 @@ def test_degenerate_poses_give_empty_systems(hip):
 
 @pytest.mark.parametrize("seed", [0, 1, 2, 3, 4, 5])
 def test_fuzz_random_geometry_vs_oracle(seed):
-    """Random image sizes (odd, not multiples of 4 or 64), intrinsics with and without skew, depth scales for which the
-    float32 double-word depth conversion is / is not exact, random poses and weights: validity and warped coordinates
+    """Random image sizes (odd, not multiples of 4 or 64), intrinsics with and without skew, several depth scales, random
+    depth-valid fractions (0.4 .. 1.0), random poses and weights: valid-point lists, validity and warped coordinates
     bit-exact, normal equations and increments within tolerance, against the oracle."""
     import dvo_amd
     from dvo_amd import _cabi
@@ -615,6 +631,11 @@ def test_fuzz_random_geometry_vs_oracle(seed):
             T = O.Pose.from_xi(xi).matrix()
             lv = O.PairLevel(gp[lvl], dp[lvl], gc[lvl], O.level_intrinsics(K, lvl), depth_scale)
             assert np.array_equal(ctx.level_intrinsics(lvl), lv.KL)
+            pts = ctx.download_points(0, lvl)                                 # valid-point list: bit exact, raster order
+            ys, xs = np.nonzero(dp[lvl])
+            assert np.array_equal(pts["x"], xs) and np.array_equal(pts["y"], ys)
+            assert np.array_equal(pts["intensity"], gp[lvl][ys, xs])
+            assert np.array_equal(pts["z"], (dp[lvl][ys, xs].astype(np.float64) * depth_scale).astype(np.float32))
             for variant, vname in ((_cabi.VARIANT_V1, "v1"), (_cabi.VARIANT_V2, "v2"), (_cabi.VARIANT_V3, "v3")):
                 if vname == "v3" and skew != 0.0:
                     continue                                   # the numba.cuda kernel has no skew term at all
