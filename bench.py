@@ -55,6 +55,8 @@ def parse_args():
     ap.add_argument("--levels", type=int, default=4)
     ap.add_argument("--iterations", type=int, default=10)
     ap.add_argument("--weighting", default="none", choices=["none", "student_t_reference", "huber"])
+    ap.add_argument("--variant", default="v1", choices=["v1", "v2", "v3"],
+                    help="v1: reference CPU default (the metric); v2: approximate_image2_gradient; v3: numba.cuda kernel semantics")
     ap.add_argument("--streams", type=int, default=4, help="independent HIP streams (sub-batches) per GPU")
     ap.add_argument("--distinct", type=int, default=0, help="distinct rendered frames (0 = batch+1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -166,7 +168,9 @@ def main():
     valid_l0 = float((depth[:-1] != 0).sum().item()) / B            # measured V per pair at level 0
 
     al = StreamedAligner(st["K"], st["depth_scale"], W, H, L, max_pairs=B, n_streams=args.streams, device=local_rank,
-                         max_iterations=args.iterations, weighting=args.weighting)
+                         max_iterations=args.iterations, weighting=args.weighting,
+                         approximate_image2_gradient=(args.variant == "v2"),
+                         reference_variant="cuda" if args.variant == "v3" else "cpu")
     counts = [B] * world
 
     def step():
@@ -234,7 +238,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": "synthetic %dx%d RGB-D stream, %d-level pyramid, %d GN iterations/level, "
                                    "%d frame pairs per GPU per step (pyramid + Sobel + valid-point-list build and device-side GN solve "
-                                   "inside the timed region), weighting=%s" % (W, H, L, args.iterations, B, args.weighting),
+                                   "inside the timed region), weighting=%s, variant=%s" % (W, H, L, args.iterations, B, args.weighting, args.variant),
                        "batch_pairs_per_gpu": B, "streams_per_gpu": args.streams, "distinct_frames": int(min(n_distinct, n_frames)),
                        "gn_iterations_per_pair": iters_total / B,
                        "gn_iterations_per_s": world * iters_total * args.steps / elapsed,
