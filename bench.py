@@ -243,7 +243,7 @@ def main():
                        "gn_iterations_per_pair": iters_total / B,
                        "gn_iterations_per_s": world * iters_total * args.steps / elapsed,
                        "parallelism": "1 independent stream per GPU, RCCL all-gather of pose records"},
-            "roofline": {"bound": "hbm", "limiter_measured": "VALU issue; measured HBM traffic (`traffic`) ~= the layout's compulsory bytes, 48 % of peak (DESIGN.md section 5)", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "roofline": {"bound": "hbm", "limiter_measured": "VALU issue, with the HBM stream (`traffic` / launch time) at 55-66 % of peak (DESIGN.md section 5)", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS,
                          "traffic": (recorded_traffic(npr, W, H) or {}).get("hbm_bytes_per_launch"),
                          "traffic_source": (recorded_traffic(npr, W, H) or {}).get("source"),
