@@ -291,3 +291,21 @@ def test_variant_v3_strict_bounds_and_types(golden_dir, frames):
     a = np.zeros(v1.shape, np.float32); a[v1] = r1.reshape(-1)
     b = np.zeros(v3.shape, np.float32); b[v3] = r3.reshape(-1)
     assert both.sum() > 0.95 * v1.sum() and np.abs(a[both] - b[both]).max() < 0.05
+
+
+def test_cpu_baseline_worker_runs_the_oracle_on_a_sample(tmp_path, frames):
+    """oracle/cpu_worker.py (bench.py's CPU-baseline leg, run as plain child processes): same poses as calling the oracle
+    directly, and the command-line form prints the seconds of its range."""
+    import subprocess
+    import sys
+    from pathlib import Path
+    import cpu_worker
+    path = tmp_path / "sample.npz"
+    g, d = frames["gray"][:2, ::4, ::4], frames["depth"][:2, ::4, ::4]           # 160x120 keeps it quick
+    K = O.level_intrinsics(frames["K"], 2)
+    np.savez(path, gray=g, depth=d, K=K, depth_scale=frames["depth_scale"])
+    secs, n = cpu_worker.run_pairs(str(path), 0, 1, 2, 2)
+    assert n == 1 and secs > 0
+    out = subprocess.run([sys.executable, str(Path(cpu_worker.__file__)), str(path), "0", "1", "2", "2"],
+                         capture_output=True, text=True, check=True)
+    assert float(out.stdout.strip().splitlines()[-1]) > 0
