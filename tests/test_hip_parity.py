@@ -294,9 +294,12 @@ def test_step_api_four_levels_vs_reference_run(frames, golden_dir, solver):
     np.testing.assert_allclose(tf.exp(), g["final_T"][0], rtol=0, atol=5e-7)
 
 
-def test_single_level_to_convergence_host(frames, golden_dir):
+@pytest.mark.parametrize("solver", ["host", "device"])
+def test_single_level_to_convergence(frames, golden_dir, solver):
+    """Free-running stop rules (|d err| < tolerance, error increase) of base_robust_dvo.py:201-232: the reference run
+    stops after 54 iterations at a single level; so do the host loop and the device-side control kernel."""
     g = np.load(golden_dir / "single_l1.npz")
-    dvo, _ = _make_dvo(frames, levels=1)
+    dvo, _ = _make_dvo(frames, levels=1, solver=solver)
     dvo.step_gray(frames["gray"][0], frames["depth"][0])
     tf = dvo.step_gray(frames["gray"][1], frames["depth"][1])
     assert dvo.last_iterations == len(g["level"])
