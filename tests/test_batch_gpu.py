@@ -195,3 +195,26 @@ def test_contexts_release_their_device_memory(vga_stream):
             free0 = free                              # after the first cycles: runtime pools are warm
         if cycle > 1:
             assert free >= free0 - (32 << 20), (cycle, free0 - free)
+
+
+@pytest.mark.parametrize("max_increased", [0, 2])
+def test_error_increase_budget_on_the_device_vs_oracle(max_increased):
+    """max_increased_steps_allowed (base_robust_dvo.py:222-224, no rollback: quirk Q8) on the device-side control: a
+    pair with a large motion (fixture frames 0 -> 4) and Huber weights, whose weighted error does go up on the way;
+    iteration count and final twist against the oracle."""
+    from pathlib import Path
+    from dvo_amd.batch import BatchAligner
+    f = np.load(Path(__file__).parent / "golden" / "frames.npz")
+    g = f["gray"][[0, 4]][:, ::2, ::2].copy()                     # 320x240: the oracle stays quick
+    d = f["depth"][[0, 4]][:, ::2, ::2].copy()
+    K = O.level_intrinsics(f["intrinsics"], 1)
+    ds = float(f["depth_scale"])
+    rec = []
+    est = O.gauss_newton(g[0], d[0], g[1], K, ds, levels=3, max_iterations=12, weighting="huber",
+                         max_increased_steps_allowed=max_increased, record=rec)
+    al = BatchAligner(K, ds, 320, 240, 3, max_pairs=1, max_iterations=12, weighting="huber",
+                      max_increased_steps_allowed=max_increased)
+    res = al.align_host(g, d)
+    al.close()
+    assert int(res["iters"][0]) == len(rec)
+    np.testing.assert_allclose(res["xi"][0], est.log(), rtol=0, atol=5e-6)
