@@ -295,6 +295,21 @@ def test_step_api_four_levels_vs_reference_run(frames, golden_dir, solver):
 
 
 @pytest.mark.parametrize("solver", ["host", "device"])
+def test_step_with_init_guess_vs_oracle(frames, solver):
+    """step(..., init_guess=T) (core/base_dense_visual_odometry.py:54-69): the estimate of pair (1, 2) started from the
+    transform found for pair (0, 1), against the oracle started from the same pose."""
+    dvo, _ = _make_dvo(frames, levels=3, max_iterations=6, solver=solver)
+    dvo.step_gray(frames["gray"][0], frames["depth"][0])
+    tf1 = dvo.step_gray(frames["gray"][1], frames["depth"][1])
+    tf2 = dvo.step_gray(frames["gray"][2], frames["depth"][2], init_guess=tf1)
+    est = O.gauss_newton(frames["gray"][1], frames["depth"][1], frames["gray"][2], frames["K"], frames["depth_scale"],
+                         levels=3, max_iterations=6, init=O.Pose.from_xi(tf1.log().reshape(6)))
+    assert dvo.last_iterations == 18
+    np.testing.assert_allclose(tf2.log().reshape(6), est.log(), rtol=0, atol=3e-6)
+    assert np.abs(tf2.log().reshape(6) - tf1.log().reshape(6)).max() > 1e-4          # it did move away from the guess
+
+
+@pytest.mark.parametrize("solver", ["host", "device"])
 def test_single_level_to_convergence(frames, golden_dir, solver):
     """Free-running stop rules (|d err| < tolerance, error increase) of base_robust_dvo.py:201-232: the reference run
     stops after 54 iterations at a single level; so do the host loop and the device-side control kernel."""
