@@ -541,6 +541,38 @@ def test_full_size_1280x960_properties():
         assert np.linalg.norm(res["xi"][0]) < 0.2 * np.linalg.norm([0.004, -0.003, 0.002, 0.002, -0.001, 0.003])
 
 
+def test_maximum_image_size_properties():
+    """The largest geometry the boundary accepts (4096 wide, (h + 1) * pitch just below 2^24: 12-bit coordinates in the
+    valid-point records, float32 tap offsets): lists against NumPy, fused reduction against the dense kernel's rows, and
+    one size further is refused."""
+    import dvo_amd
+    from dvo_amd import _cabi
+    rng = np.random.default_rng(99)
+    w, h, levels = 4096, 4078, 2                               # pitch 4112: 4079 * 4112 = 16 772 848 < 2^24
+    img, depth = _synthetic_frame(rng, h, w)
+    with pytest.raises(_cabi.DVOHipError):
+        dvo_amd.HipContext(max_w=4096, max_h=4080, max_levels=1, n_slots=2, max_pairs=1)
+    with pytest.raises(_cabi.DVOHipError):
+        dvo_amd.HipContext(max_w=4112, max_h=1000, max_levels=1, n_slots=2, max_pairs=1)
+    with dvo_amd.HipContext(max_w=w, max_h=h, max_levels=levels, n_slots=2, max_pairs=1) as ctx:
+        ctx.set_camera(3300.0, 3300.0, 2040.3, 2031.7, 0.0, 0.0002)
+        ctx.upload_frame(0, img, depth, levels)
+        ctx.upload_frame(1, img, depth, levels)
+        pts = ctx.download_points(0, 0)
+        ys, xs = np.nonzero(depth)
+        assert np.array_equal(pts["x"], xs) and np.array_equal(pts["y"], ys)      # x up to 4095, y up to 4077
+        assert np.array_equal(pts["intensity"], img[ys, xs])
+        T = O.Pose.from_xi(np.array([0.003, -0.002, 0.001, 0.001, -0.0005, 0.002])).matrix()
+        for lvl in range(levels):
+            rec = ctx.normal_equations(lvl, [0], [1], T[None])[0]
+            H, b, swr2, n, sr2 = _cabi.unpack_record(rec)
+            r, J, valid, uv, _ = ctx.residuals_jacobian(lvl, 0, 1, T)
+            assert n == int(valid.sum())
+            J64, r64 = J[valid].astype(np.float64), r[valid].astype(np.float64)
+            assert _rel(H, J64.T @ J64) < 1e-6 and _rel(b, -(J64.T @ r64)) < 1e-5
+            assert abs(swr2 - float(r64 @ r64)) < 1e-6 * swr2
+
+
 def test_projection_division_is_bit_identical_to_ieee(hip):
     """The projection's quotient (shared reciprocal + two correction steps, no v_div_scale / v_div_fixup) against the
     compiler's IEEE division on the device and against NumPy, over the operand ranges the projection sees."""
