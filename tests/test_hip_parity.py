@@ -541,6 +541,38 @@ def test_full_size_1280x960_properties():
         assert np.linalg.norm(res["xi"][0]) < 0.2 * np.linalg.norm([0.004, -0.003, 0.002, 0.002, -0.001, 0.003])
 
 
+@pytest.mark.parametrize("hw", [(1, 1), (2, 3), (5, 4), (2, 16), (17, 33), (3, 130)])
+def test_tiny_and_ragged_images_lists_and_normal_equations(hw):
+    """Degenerate geometries (single pixel, fewer pixels than a wave, one partly filled list segment, rows shorter than
+    a tile): valid-point lists bit exact, validity count and normal equations against the oracle."""
+    import dvo_amd
+    from dvo_amd import _cabi
+    h, w = hw
+    rng = np.random.default_rng(h * 1000 + w)
+    g1 = rng.integers(0, 256, size=(h, w)).astype(np.uint8)
+    g2 = rng.integers(0, 256, size=(h, w)).astype(np.uint8)
+    depth = rng.integers(3000, 9000, size=(h, w)).astype(np.uint16)
+    depth[rng.random((h, w)) < 0.3] = 0
+    K = np.array([[1.1 * max(w, 2), 0, (w - 1) / 2], [0, 1.1 * max(w, 2), (h - 1) / 2], [0, 0, 1]], dtype=np.float32)
+    T = O.Pose.from_xi(np.array([0.001, -0.002, 0.001, 0.002, 0.001, -0.003])).matrix()
+    with dvo_amd.HipContext(max_w=w, max_h=h, max_levels=1, n_slots=2, max_pairs=1) as ctx:
+        ctx.set_camera(K[0, 0], K[1, 1], K[0, 2], K[1, 2], 0.0, 0.0002)
+        ctx.upload_frame(0, g1, depth, 1)
+        ctx.upload_frame(1, g2, depth, 1)
+        pts = ctx.download_points(0, 0)
+        ys, xs = np.nonzero(depth)
+        assert np.array_equal(pts["x"], xs) and np.array_equal(pts["y"], ys) and np.array_equal(pts["intensity"], g1[ys, xs])
+        lv = O.PairLevel(g1, depth, g2, O.level_intrinsics(K, 0), 0.0002)
+        ro, Jo, _, valid_o = O.residuals_and_jacobian(lv, T, "v1")
+        Ho, bo, so, no = O.normal_equations(ro, Jo)
+        H, b, swr2, n, sr2 = _cabi.unpack_record(ctx.normal_equations(0, [0], [1], T[None])[0])
+        assert n == no == int(valid_o.sum())
+        if no:
+            assert _rel(H, Ho) < 1e-5 and abs(swr2 - so) <= 1e-5 * max(so, 1e-9)
+        else:
+            assert not H.any() and swr2 == 0.0
+
+
 def test_maximum_image_size_properties():
     """The largest geometry the boundary accepts (4096 wide, (h + 1) * pitch just below 2^24: 12-bit coordinates in the
     valid-point records, float32 tap offsets): lists against NumPy, fused reduction against the dense kernel's rows, and
