@@ -81,6 +81,8 @@ struct dvo_ctx {
     uint8_t* d_stage_img = nullptr;      // staging for host->device image uploads (bgr needs 3 B/px + depth)
     uint8_t* d_batch_stage = nullptr;    // staging of dvo_upload_frames (whole batches), grown on demand
     size_t batch_stage_bytes = 0;
+    double* d_scale1 = nullptr;          // Student-t device solve: per-workgroup sums of the two scale passes
+    double* d_scale2 = nullptr;
     float* d_rcache = nullptr;           // Student-t device solve: residuals kept between the scale passes [max_pairs][max_w*max_h]
     float* d_dense = nullptr;            // dense writer outputs: r[npix] J[6 npix] uv[2 npix] + valid
     double* d_trace = nullptr;
@@ -290,6 +292,9 @@ int fill_reduce_params(dvo_ctx* ctx, int level, int n_pairs, int w, int h, DvoRe
     p->list_count = ctx->d_list_count;
     p->level = level;
     p->rcache = nullptr;
+    p->scale_out = nullptr;
+    p->scale1 = nullptr;
+    p->scale2 = nullptr;
     {
         const char* e = getenv("DVO_XCD_REMAP");
         p->xcd_remap = (e && e[0] == '1') ? 1 : 0;   // measured slower on MI355X, off by default
@@ -484,7 +489,7 @@ void dvo_destroy(dvo_ctx* ctx)
     if (ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);
     void* dev[] = {ctx->d_slots, ctx->d_prev, ctx->d_cur, ctx->d_T, ctx->d_Tinit, ctx->d_wparam, ctx->d_active, ctx->d_partials,
                    ctx->d_out, ctx->d_state, ctx->d_xi, ctx->d_iters, ctx->d_err, ctx->d_stage_img, ctx->d_dense, ctx->d_trace, ctx->d_frame_slots, ctx->d_prior, ctx->d_batch_stage,
-                   ctx->d_list_count, ctx->d_seg_counts, ctx->d_rcache};
+                   ctx->d_list_count, ctx->d_seg_counts, ctx->d_rcache, ctx->d_scale1, ctx->d_scale2};
     for (void* p : dev) if (p) (void)hipFree(p);
     void* host[] = {ctx->hs.prev, ctx->hs.cur, ctx->hs.T, ctx->hs.wparam, ctx->hs.out, ctx->hs.xi, ctx->hs.iters, ctx->hs.err, ctx->h_frame_slots, ctx->h_prior};
     for (void* p : host) if (p) (void)hipHostFree(p);
@@ -931,15 +936,29 @@ static int record_solve(dvo_ctx* ctx, const SolveKey& k, const float* d_init)
                 // the two IRLS scale passes the reference's loop takes (weighter/t_weighter.py:24-32)
                 // (the first pass keeps the residuals of this pose; the second sums them again under the new lambda)
                 p.rcache = ctx->d_rcache;
-                for (int pass = 1; pass <= 2; ++pass) {
-                    if (pass == 1 || ctx->d_rcache == nullptr) HIP_TRY(ctx, launch_reduce_profiled(ctx, p, level, variant, 1, 1));
-                    else HIP_TRY(ctx, dvo_launch_scale_cached(p, ctx->stream));
-                    sp.phase = pass;
-                    HIP_TRY(ctx, dvo_launch_solve(sp, ctx->stream));
+                if (ctx->d_rcache != nullptr && ctx->d_scale1 != nullptr && getenv("DVO_ST_SOLVE_PHASES") == nullptr) {
+                    // no control launch between the three passes: each kernel derives its lambda from the per-workgroup sums
+                    // of the passes before it (same summation order as k_solve => same lambda, bit for bit)
+                    p.scale_out = ctx->d_scale1;
+                    HIP_TRY(ctx, launch_reduce_profiled(ctx, p, level, variant, 1, 1));
+                    p.scale_out = ctx->d_scale2;
+                    p.scale1 = ctx->d_scale1;
+                    HIP_TRY(ctx, dvo_launch_scale_cached(p, ctx->stream));
+                    p.scale_out = nullptr;
+                    p.scale2 = ctx->d_scale2;
+                } else {
+                    for (int pass = 1; pass <= 2; ++pass) {
+                        if (pass == 1 || ctx->d_rcache == nullptr) HIP_TRY(ctx, launch_reduce_profiled(ctx, p, level, variant, 1, 1));
+                        else HIP_TRY(ctx, dvo_launch_scale_cached(p, ctx->stream));
+                        sp.phase = pass;
+                        HIP_TRY(ctx, dvo_launch_solve(sp, ctx->stream));
+                    }
                 }
                 p.rcache = nullptr;
             }
             HIP_TRY(ctx, launch_reduce_profiled(ctx, p, level, variant, weight_mode, 0));
+            p.scale1 = nullptr;
+            p.scale2 = nullptr;
             sp.phase = 0;
             HIP_TRY(ctx, dvo_launch_solve(sp, ctx->stream));
         }
@@ -970,6 +989,13 @@ int dvo_solve_batch_enqueue(dvo_ctx* ctx, int n_pairs, const int* prev_slot, con
         if (hipMalloc((void**)&ctx->d_rcache, (size_t)ctx->max_pairs * ctx->max_w * ctx->max_h * sizeof(float)) != hipSuccess) {
             (void)hipGetLastError();
             ctx->d_rcache = nullptr;
+        }
+        const size_t nsc = ctx->partials_doubles / DVO_STRIDE;           // one double per (pair, workgroup)
+        if (ctx->d_rcache != nullptr && (hipMalloc((void**)&ctx->d_scale1, nsc * sizeof(double)) != hipSuccess ||
+                                         hipMalloc((void**)&ctx->d_scale2, nsc * sizeof(double)) != hipSuccess)) {
+            (void)hipGetLastError();
+            if (ctx->d_scale1) (void)hipFree(ctx->d_scale1);
+            ctx->d_scale1 = ctx->d_scale2 = nullptr;
         }
     }
     const float* d_init = nullptr;

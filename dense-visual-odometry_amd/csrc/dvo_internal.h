@@ -62,6 +62,9 @@ struct DvoReduceParams {
     int n_pairs;
     const int* list_count;      // [n_slots][DVO_LIST_LEVELS] number of records in each slot's list
     int level;
+    double* scale_out;          // Student-t device solve: the scale passes write one double per workgroup here ([n_pairs][blocks_per_pair])
+    const double* scale1;       // ... and the following kernels derive lambda from those sums themselves (no control launch
+    const double* scale2;       //     between the three passes of an iteration); all null: lambda comes from wparam
     float* rcache;              // Student-t scale passes: [n_pairs][g.npix] residual of every record of the current pose
                                 // (NaN: out of bounds), written by the first pass and read by the second; or null
 };

@@ -810,6 +810,35 @@ __device__ __forceinline__ void block_reduce_terms(const float* acc, double* out
 #ifndef DVO_REDUCE_WAVES_PER_SIMD
 #define DVO_REDUCE_WAVES_PER_SIMD 4
 #endif
+// Sum of the per-workgroup scale sums of one pair in exactly the order sum_partials_block + k_solve use (eight interleaved
+// running sums, then those in order), so that lambda derived here is bit-identical to the one the control kernel derives.
+__device__ __forceinline__ double scale_sum_ordered(const double* __restrict__ x, int nblk)
+{
+    double t = 0.0;
+    for (int g = 0; g < 8; ++g) {
+        double s = 0.0;
+        for (int b = g; b < nblk; b += 8) s += x[b];
+        t += s;
+    }
+    return t;
+}
+
+// Student-t IRLS of one iteration (weighter/t_weighter.py:24-32) from the sums of the two scale passes: lambda1 = 1 / S1;
+// converged (|lambda1 - lambda0| < 1e-3) keeps it, otherwise lambda2 = 1 / S2.  with_second = false: the lambda the second
+// pass itself runs under (lambda1).  One lane computes, the workgroup shares it.
+__device__ __forceinline__ double student_t_lambda(const DvoReduceParams& p, int pair, double lambda0, bool with_second)
+{
+    __shared__ double lam_sh;
+    if (threadIdx.x == 0) {
+        const size_t o = (size_t)pair * p.blocks_per_pair;
+        double lam = 1.0 / scale_sum_ordered(p.scale1 + o, p.blocks_per_pair);
+        if (with_second && !(fabs(lam - lambda0) < 1e-3)) lam = 1.0 / scale_sum_ordered(p.scale2 + o, p.blocks_per_pair);
+        lam_sh = lam;
+    }
+    __syncthreads();
+    return lam_sh;
+}
+
 // TAG only names the instantiation so that rocprofv3 --stats lists these dispatches on their own line; codegen is
 // identical.  0: coarser levels, 1: level 0, 2: level 0 while the ctx is in profiling mode (bench.py's roofline leg).
 template <int VARIANT, int WMODE, bool SCALE_PASS, int TAG, bool SKEW>
@@ -840,7 +869,13 @@ __global__ __launch_bounds__(DVO_BLOCK, (VARIANT == 2) ? 2 : DVO_REDUCE_WAVES_PE
     for (int i = 0; i < 12; ++i) T[i] = p.T[pair * 12 + i];
     const DvoLevelCam& cam = p.cam;
     float wpar = 0.0f;
-    if (WMODE != 0) wpar = (float)p.wparam[pair];
+    if (WMODE != 0) {
+        double lam = p.wparam[pair];
+        if constexpr (WMODE == 1 && !SCALE_PASS) {
+            if (p.scale1 != nullptr) lam = student_t_lambda(p, pair, lam, true);
+        }
+        wpar = (float)lam;
+    }
 
     float acc[NACC];
 #pragma unroll
@@ -963,7 +998,9 @@ __global__ __launch_bounds__(DVO_BLOCK, (VARIANT == 2) ? 2 : DVO_REDUCE_WAVES_PE
         const double sw = wave_sum((double)acc[0]);
         if ((threadIdx.x & 63) == 0) lds1[threadIdx.x >> 6] = sw;
         __syncthreads();
-        if (threadIdx.x < DVO_STRIDE) {
+        if (p.scale_out != nullptr) {
+            if (threadIdx.x == 0) p.scale_out[(size_t)pair * p.blocks_per_pair + blk] = (lds1[0] + lds1[1]) + (lds1[2] + lds1[3]);
+        } else if (threadIdx.x < DVO_STRIDE) {
             double tot = 0.0;
             if (threadIdx.x == 0) tot = (lds1[0] + lds1[1]) + (lds1[2] + lds1[3]);
             p.partials[((size_t)pair * p.blocks_per_pair + blk) * DVO_STRIDE + threadIdx.x] = tot;
@@ -987,7 +1024,7 @@ __global__ __launch_bounds__(DVO_BLOCK) void k_scale_cached(const DvoReduceParam
     const int count = p.list_count[p.prev_slot[pair] * DVO_LIST_LEVELS + p.level];
     const int gstride = p.blocks_per_pair * (DVO_BLOCK / 64) * (64 * DVO_PX_PER_THREAD);
     const int rec0 = (blk * (DVO_BLOCK / 64) + wave_) * (64 * DVO_PX_PER_THREAD);
-    const float wpar = (float)p.wparam[pair];
+    const float wpar = (float)((p.scale1 != nullptr) ? student_t_lambda(p, pair, 0.0, false) : p.wparam[pair]);
     const float* rc_in = p.rcache + (size_t)pair * p.g.npix;
     float acc = 0.0f;
     for (int grp = 0; grp < p.groups_per_block; ++grp) {
@@ -1011,7 +1048,9 @@ __global__ __launch_bounds__(DVO_BLOCK) void k_scale_cached(const DvoReduceParam
     const double sw = wave_sum((double)acc);
     if ((threadIdx.x & 63) == 0) lds1[threadIdx.x >> 6] = sw;
     __syncthreads();
-    if (threadIdx.x < DVO_STRIDE) {
+    if (p.scale_out != nullptr) {
+        if (threadIdx.x == 0) p.scale_out[(size_t)pair * p.blocks_per_pair + blk] = (lds1[0] + lds1[1]) + (lds1[2] + lds1[3]);
+    } else if (threadIdx.x < DVO_STRIDE) {
         double tot = 0.0;
         if (threadIdx.x == 0) tot = (lds1[0] + lds1[1]) + (lds1[2] + lds1[3]);
         p.partials[((size_t)pair * p.blocks_per_pair + blk) * DVO_STRIDE + threadIdx.x] = tot;

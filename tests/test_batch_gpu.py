@@ -96,22 +96,25 @@ def test_huber_and_student_t_device_vs_oracle(vga_stream):
             np.testing.assert_allclose(res["xi"][k], est.log(), rtol=0, atol=2e-6)
 
 
-def test_student_t_residual_cache_is_bit_identical_to_recomputation(vga_stream, monkeypatch):
-    """The second Student-t scale pass of an iteration sums the residuals the first pass kept; DVO_NO_RCACHE makes it
-    recompute them (the pre-cache behaviour).  Same record->lane map and summation order => identical poses."""
+def test_student_t_fast_path_is_bit_identical_to_the_plain_one(vga_stream, monkeypatch):
+    """Student-t device solve: (default) the second scale pass sums the residuals the first pass kept and every kernel
+    derives its lambda from the per-workgroup sums of the passes before it; DVO_ST_SOLVE_PHASES keeps the cache but
+    runs the control kernel after each pass; DVO_NO_RCACHE also recomputes the residuals (the original flow).  Same
+    record->lane map and summation orders => identical poses."""
     from dvo_amd.batch import BatchAligner
     st = vga_stream
     out = []
-    for no_cache in (False, True):
-        if no_cache:
-            monkeypatch.setenv("DVO_NO_RCACHE", "1")
-        else:
-            monkeypatch.delenv("DVO_NO_RCACHE", raising=False)
+    for env in ((), ("DVO_ST_SOLVE_PHASES",), ("DVO_NO_RCACHE",)):
+        monkeypatch.delenv("DVO_ST_SOLVE_PHASES", raising=False)
+        monkeypatch.delenv("DVO_NO_RCACHE", raising=False)
+        for k in env:
+            monkeypatch.setenv(k, "1")
         al = BatchAligner(st["K"], st["depth_scale"], 640, 480, 4, max_pairs=8, max_iterations=6,
                           weighting="student_t_reference")
         out.append(al.align_host(st["gray"], st["depth"]))
         al.close()
-    assert np.array_equal(out[0]["xi"], out[1]["xi"]) and np.array_equal(out[0]["err"], out[1]["err"])
+    for o in out[1:]:
+        assert np.array_equal(out[0]["xi"], o["xi"]) and np.array_equal(out[0]["err"], o["err"])
 
 
 def test_config3_1280x960_five_levels_huber():
