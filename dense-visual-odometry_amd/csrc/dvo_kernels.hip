@@ -810,29 +810,31 @@ __device__ __forceinline__ void block_reduce_terms(const float* acc, double* out
 #ifndef DVO_REDUCE_WAVES_PER_SIMD
 #define DVO_REDUCE_WAVES_PER_SIMD 4
 #endif
-// Sum of the per-workgroup scale sums of one pair in exactly the order sum_partials_block + k_solve use (eight interleaved
-// running sums, then those in order), so that lambda derived here is bit-identical to the one the control kernel derives.
-__device__ __forceinline__ double scale_sum_ordered(const double* __restrict__ x, int nblk)
-{
-    double t = 0.0;
-    for (int g = 0; g < 8; ++g) {
-        double s = 0.0;
-        for (int b = g; b < nblk; b += 8) s += x[b];
-        t += s;
-    }
-    return t;
-}
-
-// Student-t IRLS of one iteration (weighter/t_weighter.py:24-32) from the sums of the two scale passes: lambda1 = 1 / S1;
-// converged (|lambda1 - lambda0| < 1e-3) keeps it, otherwise lambda2 = 1 / S2.  with_second = false: the lambda the second
-// pass itself runs under (lambda1).  One lane computes, the workgroup shares it.
+// Student-t IRLS of one iteration (weighter/t_weighter.py:24-32) from the per-workgroup sums of the two scale passes:
+// lambda1 = 1 / S1; converged (|lambda1 - lambda0| < 1e-3) keeps it, otherwise lambda2 = 1 / S2.  with_second = false: the
+// lambda the second pass itself runs under (lambda1).  S is summed in exactly the order sum_partials_block + k_solve use
+// (eight interleaved running sums, then those in order: lanes 0-7 for S1, 8-15 for S2), so lambda is bit-identical to the
+// one the control kernel derives; the workgroup shares the result.
 __device__ __forceinline__ double student_t_lambda(const DvoReduceParams& p, int pair, double lambda0, bool with_second)
 {
+    __shared__ double sg[16];
     __shared__ double lam_sh;
-    if (threadIdx.x == 0) {
-        const size_t o = (size_t)pair * p.blocks_per_pair;
-        double lam = 1.0 / scale_sum_ordered(p.scale1 + o, p.blocks_per_pair);
-        if (with_second && !(fabs(lam - lambda0) < 1e-3)) lam = 1.0 / scale_sum_ordered(p.scale2 + o, p.blocks_per_pair);
+    const int t = threadIdx.x;
+    if (t < (with_second ? 16 : 8)) {
+        const double* x = ((t < 8) ? p.scale1 : p.scale2) + (size_t)pair * p.blocks_per_pair;
+        double s = 0.0;
+        for (int b = t & 7; b < p.blocks_per_pair; b += 8) s += x[b];
+        sg[t] = s;
+    }
+    __syncthreads();
+    if (t == 0) {
+        double s1 = 0.0, s2 = 0.0;
+        for (int k = 0; k < 8; ++k) s1 += sg[k];
+        double lam = 1.0 / s1;
+        if (with_second && !(fabs(lam - lambda0) < 1e-3)) {
+            for (int k = 0; k < 8; ++k) s2 += sg[8 + k];
+            lam = 1.0 / s2;
+        }
         lam_sh = lam;
     }
     __syncthreads();

@@ -29,3 +29,11 @@ for solver in ("host", "device"):
         dvo.step_gray(st["gray"][k], st["depth"][k])
         ts.append(time.perf_counter() - t0)
     print("solver=%s: step_gray() ms per frame: median %.2f min %.2f" % (solver, 1e3 * np.median(ts[1:]), 1e3 * min(ts[1:])))
+# Student-t reference weighter (use_weighter=True), device solve
+dvo = dvo_amd.get_dvo("robust-dvo", cam, dvo_amd.Se3.identity(), levels=4, max_iterations=10, solver="device", use_weighter=True)
+ts = []
+for k in range(12):
+    t0 = time.perf_counter()
+    dvo.step_gray(st["gray"][k], st["depth"][k])
+    ts.append(time.perf_counter() - t0)
+print("solver=device, use_weighter=True: step_gray() ms per frame: median %.2f min %.2f" % (1e3 * np.median(ts[1:]), 1e3 * min(ts[1:])))
