@@ -59,6 +59,8 @@ def parse_args():
                     help="v1: reference CPU default (the metric); v2: approximate_image2_gradient; v3: numba.cuda kernel semantics")
     ap.add_argument("--streams", type=int, default=4, help="independent HIP streams (sub-batches) per GPU")
     ap.add_argument("--distinct", type=int, default=0, help="distinct rendered frames (0 = batch+1)")
+    ap.add_argument("--spawn", action="store_true",
+                    help="start the ranks through the launcher even for --gpus 1 (rehearses the multi-GPU entry on one GPU)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-pairs", type=int, default=32, help="frame pairs of the CPU baseline sample (~0.35 s each)")
     return ap.parse_args()
@@ -134,22 +136,39 @@ def fixture_ate(device):
 
 def main():
     args = parse_args()
+    from dvo_amd import launch
+
+    # `python bench.py --gpus N` starts its own N ranks (one process per GPU) when no launcher did: fresh child
+    # processes under torch.distributed.run, spawned before this process has made any HIP call; rank 0's JSON line is
+    # relayed through the inherited stdout.  Fewer than N visible devices is an error, never a 1-GPU measurement.
+    if not launch.started_by_launcher() and (args.gpus > 1 or args.spawn):
+        try:
+            rc = launch.launch_ranks(args.gpus, str(Path(__file__).resolve()), [a for a in sys.argv[1:] if a != "--spawn"])
+        except launch.LaunchError as e:
+            raise SystemExit("bench.py: %s" % e)
+        raise SystemExit(rc)
+
     import numpy as np
     import torch
     import torch.distributed as dist
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus:
-        if rank == 0:
-            print("warning: --gpus %d but WORLD_SIZE=%d; using WORLD_SIZE" % (args.gpus, world), file=sys.stderr)
+    rank, local_rank, world = launch.rank_env()
+    try:
+        launch.check_world(args.gpus)
+    except launch.LaunchError as e:
+        raise SystemExit("bench.py: %s" % e)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (no CPU fallback)")
+    if local_rank >= torch.cuda.device_count():
+        raise SystemExit("bench.py: rank %d has no GPU (local rank %d, %d device(s) visible)" % (rank, local_rank, torch.cuda.device_count()))
     torch.cuda.set_device(local_rank)
-    use_dist = world > 1 or os.environ.get("DVO_BENCH_FORCE_DIST") == "1"     # (the env var rehearses the RCCL path on 1 GPU)
+    # under a launcher the process group is always formed (also for one rank: the same RCCL code path as N ranks)
+    use_dist = launch.started_by_launcher() or os.environ.get("DVO_BENCH_FORCE_DIST") == "1"
     if use_dist:
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        world = dist.get_world_size()                      # the ranks that actually joined
+        if world != args.gpus:
+            raise SystemExit("bench.py: %d ranks joined the process group, --gpus %d" % (world, args.gpus))
 
     from dvo_amd import synthetic
     from dvo_amd.batch import StreamedAligner, pose_records, allgather_poses
@@ -230,7 +249,9 @@ def main():
             "metric": "frame-pairs/s (full pyramid GN solve) VGA RGB-D",
             "value": pairs_per_s,
             "unit": "frame-pairs/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "n_gpus": world, "ranks_joined": (dist.get_world_size() if use_dist else 1),
+            "collective": ("RCCL all-gather of pose records, world size %d" % dist.get_world_size()) if use_dist else "none (single process)",
+            "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32",

@@ -115,6 +115,17 @@ struct dvo_ctx {
     struct GraphEntry { SolveKey key; hipGraphExec_t exec; };
     std::vector<GraphEntry> graphs;
     bool graphs_enabled = true;
+    // tuning / debugging knobs, read from the environment ONCE at dvo_create (never on the per-call path; a captured
+    // solve graph bakes them in, so they must not change under it)
+    struct Knobs {
+        int xcd_remap = 0;          // DVO_XCD_REMAP=1: XCD-aware logical block order (measured slower)
+        int max_groups = 16;        // DVO_MAX_GROUPS
+        int target_blocks = 1024;   // DVO_TARGET_BLOCKS
+        bool st_solve_phases = false;   // DVO_ST_SOLVE_PHASES: Student-t device solve with control launches between the passes
+        bool no_rcache = false;         // DVO_NO_RCACHE: second Student-t scale pass recomputes the residuals
+        bool ingest_unfused = false;    // DVO_INGEST_UNFUSED: separate ingest kernels for every level (tests)
+        bool fused_solve = true;        // DVO_FUSED_SOLVE=0: control step as its own launch (k_solve) instead of in k_reduce
+    } knobs;
     char err[512] = "";
 };
 
@@ -295,20 +306,13 @@ int fill_reduce_params(dvo_ctx* ctx, int level, int n_pairs, int w, int h, DvoRe
     p->scale_out = nullptr;
     p->scale1 = nullptr;
     p->scale2 = nullptr;
-    {
-        const char* e = getenv("DVO_XCD_REMAP");
-        p->xcd_remap = (e && e[0] == '1') ? 1 : 0;   // measured slower on MI355X, off by default
-    }
+    p->xcd_remap = ctx->knobs.xcd_remap;
     // more pixels per workgroup on the big levels amortises the 30-term cross-lane reduction
     // groups so that the launch still has a few thousand workgroups: (pixels of the batch / 1024) / ~4096
     {
         const long long total_groups = (long long)n_pairs * ((g[level].npix + DVO_PX_PER_BLOCK - 1) / DVO_PX_PER_BLOCK);
-        int gmax = 16;
-        const char* e = getenv("DVO_MAX_GROUPS");
-        if (e && atoi(e) > 0) gmax = atoi(e);
-        int target = 1024;                       // measured on MI355X: small levels gain from fewer, longer workgroups (L2 27 -> 21 us)
-        const char* tb = getenv("DVO_TARGET_BLOCKS");
-        if (tb && atoi(tb) > 0) target = atoi(tb);
+        const int gmax = ctx->knobs.max_groups;
+        const int target = ctx->knobs.target_blocks;   // measured on MI355X: small levels gain from fewer, longer workgroups (L2 27 -> 21 us)
         int gp = (int)(total_groups / target);
         if (gp < 1) gp = 1;
         if (gp > gmax) gp = gmax;
@@ -350,6 +354,7 @@ int build_pyramid_on_device(dvo_ctx* ctx, int slot, int w, int h, int levels)
     p.depth_scale = ctx->depth_scale;
     p.list_count = ctx->d_list_count;
     p.seg_counts = ctx->d_seg_counts;
+    p.allow_fused = ctx->knobs.ingest_unfused ? 0 : 1;
     level_geometry(w, h, levels, p.g, nullptr);
     int rc = stage_frame_slots(ctx, &slot, 1);
     if (rc) return rc;
@@ -464,6 +469,17 @@ int dvo_create(int device, int max_w, int max_h, int max_levels, int n_slots, in
     {
         const char* e = getenv("DVO_GRAPH");
         ctx->graphs_enabled = !(e && e[0] == '0');
+        e = getenv("DVO_XCD_REMAP");
+        ctx->knobs.xcd_remap = (e && e[0] == '1') ? 1 : 0;
+        e = getenv("DVO_MAX_GROUPS");
+        if (e && atoi(e) > 0) ctx->knobs.max_groups = atoi(e);
+        e = getenv("DVO_TARGET_BLOCKS");
+        if (e && atoi(e) > 0) ctx->knobs.target_blocks = atoi(e);
+        ctx->knobs.st_solve_phases = getenv("DVO_ST_SOLVE_PHASES") != nullptr;
+        ctx->knobs.no_rcache = getenv("DVO_NO_RCACHE") != nullptr;
+        ctx->knobs.ingest_unfused = getenv("DVO_INGEST_UNFUSED") != nullptr;
+        e = getenv("DVO_FUSED_SOLVE");
+        ctx->knobs.fused_solve = !(e && e[0] == '0');
     }
 #undef CREATE_TRY
     *out = ctx;
@@ -521,6 +537,14 @@ int dvo_set_camera(dvo_ctx* ctx, float fx, float fy, float cx, float cy, float s
         return fail(ctx, DVO_ERR_INVALID_ARG, "dvo_set_camera: need fx, fy > 0 and depth_scale >= 0");
     if (!ctx->have_camera || depth_scale != ctx->depth_scale)
         for (SlotInfo& si : ctx->slots) si.lists = false;      // their valid-point lists hold z for the old scale
+    // a captured solve graph holds the level intrinsics (and the skew / no-skew kernel choice) as kernel arguments:
+    // graphs recorded under the old camera must not be replayed
+    if (!ctx->graphs.empty()) {
+        HIP_TRY(ctx, hipSetDevice(ctx->device));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        for (auto& g : ctx->graphs) (void)hipGraphExecDestroy(g.exec);
+        ctx->graphs.clear();
+    }
     ctx->fx = fx; ctx->fy = fy; ctx->cx = cx; ctx->cy = cy; ctx->skew = skew; ctx->depth_scale = depth_scale;
     ctx->have_camera = true;
     return DVO_OK;
@@ -598,6 +622,7 @@ int dvo_upload_frames_device(dvo_ctx* ctx, int n_frames, const int* slots, const
     p.depth_scale = ctx->depth_scale;
     p.list_count = ctx->d_list_count;
     p.seg_counts = ctx->d_seg_counts;
+    p.allow_fused = ctx->knobs.ingest_unfused ? 0 : 1;
     level_geometry(w, h, levels, p.g, nullptr);
     {
         int rc = stage_frame_slots(ctx, slots, n_frames);
@@ -926,7 +951,7 @@ static int record_solve(dvo_ctx* ctx, const SolveKey& k, const float* d_init)
         sp.max_increased = max_increased_steps_allowed;
         sp.weight_mode = weight_mode;
         sp.weight_param = weight_param;
-        sp.inv_sigma = k.inv_sigma;
+        sp.inv_sigma = k.has_last ? k.inv_sigma : 0.0;   // no previous transform: the reference skips the prior (base_robust_dvo.py:190)
         sp.trace = ctx->d_trace;
         sp.trace_stride = DVO_STRIDE + 18;
         sp.trace_cap = ctx->trace_cap;
@@ -936,7 +961,7 @@ static int record_solve(dvo_ctx* ctx, const SolveKey& k, const float* d_init)
                 // the two IRLS scale passes the reference's loop takes (weighter/t_weighter.py:24-32)
                 // (the first pass keeps the residuals of this pose; the second sums them again under the new lambda)
                 p.rcache = ctx->d_rcache;
-                if (ctx->d_rcache != nullptr && ctx->d_scale1 != nullptr && getenv("DVO_ST_SOLVE_PHASES") == nullptr) {
+                if (ctx->d_rcache != nullptr && ctx->d_scale1 != nullptr && !ctx->knobs.st_solve_phases) {
                     // no control launch between the three passes: each kernel derives its lambda from the per-workgroup sums
                     // of the passes before it (same summation order as k_solve => same lambda, bit for bit)
                     p.scale_out = ctx->d_scale1;
@@ -983,7 +1008,7 @@ int dvo_solve_batch_enqueue(dvo_ctx* ctx, int n_pairs, const int* prev_slot, con
     if (rc) return rc;
     rc = stage_pairs(ctx, n_pairs, prev_slot, cur_slot, nullptr, nullptr);
     if (rc) return rc;
-    if (weight_mode == DVO_WEIGHT_STUDENT_T && ctx->d_rcache == nullptr && getenv("DVO_NO_RCACHE") == nullptr) {
+    if (weight_mode == DVO_WEIGHT_STUDENT_T && ctx->d_rcache == nullptr && !ctx->knobs.no_rcache) {
         // residual cache of the scale passes (allocated on first use, outside any graph capture); without it the second
         // pass recomputes the residuals
         if (hipMalloc((void**)&ctx->d_rcache, (size_t)ctx->max_pairs * ctx->max_w * ctx->max_h * sizeof(float)) != hipSuccess) {

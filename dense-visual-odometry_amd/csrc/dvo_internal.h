@@ -127,6 +127,7 @@ struct DvoBatchIngestParams {
     double depth_scale;          // for the valid-point lists
     int* list_count;             // [n_slots][DVO_LIST_LEVELS]
     int* seg_counts;             // scratch [n_frames][sum of g[l].nseg]: per-segment counts, then exclusive offsets
+    int allow_fused;             // 0: separate kernels for every level (DVO_INGEST_UNFUSED, tests)
 };
 
 // launch wrappers implemented in dvo_kernels.hip -------------------------------------------------

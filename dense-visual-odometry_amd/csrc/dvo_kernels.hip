@@ -517,7 +517,7 @@ hipError_t dvo_launch_batch_ingest(const DvoBatchIngestParams& p, hipStream_t s)
     int segs = 0;
     for (int l = 0; l < p.levels; ++l) segs += p.g[l].nseg;
     const bool aligned = ((reinterpret_cast<uintptr_t>(p.src_gray) | reinterpret_cast<uintptr_t>(p.src_depth)) & 15u) == 0;
-    const bool allow_fused = getenv("DVO_INGEST_UNFUSED") == nullptr;
+    const bool allow_fused = p.allow_fused != 0;
     hipError_t e = hipMemsetAsync(p.seg_counts, 0, (size_t)nf * segs * sizeof(int), s);    // fused levels accumulate their counts
     if (e != hipSuccess) return e;
     bool have_planes = (p.src_gray == nullptr);          // planes of the current level already in the slots?

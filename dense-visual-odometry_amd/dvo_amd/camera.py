@@ -3,7 +3,7 @@
 `intrinsics`, `depth_scale`.
 
 The HIP kernels do their own back-projection / projection on the device (csrc/dvo_kernels.hip,
-`dvo_pixel`); the NumPy `deproject` / `project` here exist for API parity (tools and tests that call
+`dvo_geo`); the NumPy `deproject` / `project` here exist for API parity (tools and tests that call
 them directly) and spell out the float32 operation order the kernels use.  There is no np_cache
 (utils/numpy_cache.py): device-resident pyramids make the memoisation moot.
 """

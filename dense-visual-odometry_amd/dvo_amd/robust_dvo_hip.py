@@ -172,14 +172,17 @@ class RobustDVOHIP:
         else:
             self._set_pyramid_views()
             transform = self._gauss_newton(init_guess)
-        self._last_pose = self._current_pose.copy()
-        self._last_estimated_transform = transform.copy()
-        self._current_pose = self._current_pose * transform.inverse()
-        if self._have_prev:
-            self._prev_slot, self._cur_slot = self._cur_slot, self._prev_slot
-        self._have_prev = True
-        self._gray_image_prev = True
-        self._depth_image_prev = True
+        if transform is not None:                                   # core/base_dense_visual_odometry.py:76
+            self._last_pose = self._current_pose.copy()
+            self._last_estimated_transform = transform.copy()
+            self._current_pose = self._current_pose * transform.inverse()
+            if self._have_prev:
+                self._prev_slot, self._cur_slot = self._cur_slot, self._prev_slot
+            self._have_prev = True
+            self._gray_image_prev = True
+            self._depth_image_prev = True
+        else:
+            logger.warning("DVO could not estimate transform, trying luck on next frame..")
         return transform
 
     # -- the four backend hooks (base_robust_dvo.py:91-135) ------------------------------------------------
@@ -340,11 +343,16 @@ class RobustDVOHIP:
         return Se3.from_se3(res["xi"][0].reshape(6, 1))
 
 
-def robust_dvo_factory(use_gpu: bool = True, backend: str = "hip", **kwargs):
-    """Counterpart of core/robust_dense_visual_odometry/__init__.py:5-25.  This package ships one backend;
-    `use_gpu=False` / another backend name is an error rather than a silent CPU path."""
-    if backend != "hip" or not use_gpu:
-        raise ValueError("dvo_amd only provides the MI355X backend (backend='hip', use_gpu=True)")
+def robust_dvo_factory(use_gpu: bool = False, backend: str = "hip", **kwargs):
+    """Counterpart of core/robust_dense_visual_odometry/__init__.py:5-25 (same default: `use_gpu=False`).  This package
+    ships one backend, so the reference's CPU / numba.cuda switch selects which of the reference's two behaviours the HIP
+    kernels reproduce, never where they run: `use_gpu=False` -> RobustDVOCPU semantics (V1 / V2), `use_gpu=True` with
+    `reference_variant="cuda"` given explicitly -> its numba.cuda kernel's (V3).  A reference config JSON therefore loads
+    unchanged; there is still no CPU execution path (a missing device raises)."""
+    if backend != "hip":
+        raise ValueError("dvo_amd only provides the MI355X backend (backend='hip'), got '{}'".format(backend))
+    if not use_gpu:
+        logger.info("use_gpu=False: reproducing the reference's CPU backend semantics on the MI355X (dvo_amd has no CPU path)")
     return RobustDVOHIP(**kwargs)
 
 

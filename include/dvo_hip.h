@@ -92,7 +92,8 @@ int dvo_synchronize(dvo_ctx* ctx);
  * Call it BEFORE uploading frames (the reference takes the camera model in the constructor): the ingest stores
  * z = depth * depth_scale with every depth-valid pixel.  A frame uploaded earlier, or under another depth_scale, keeps
  * its pyramid but the alignment calls refuse it as the previous frame of a pair (DVO_ERR_BAD_STATE) until it is
- * uploaded again; changing only the intrinsics needs no re-upload. */
+ * uploaded again; changing only the intrinsics needs no re-upload (cached launch graphs of dvo_solve_batch are dropped,
+ * so the next solve uses the new intrinsics). */
 int dvo_set_camera(dvo_ctx* ctx, float fx, float fy, float cx, float cy, float skew, double depth_scale);
 /* Writes the 3x4 float32 level intrinsics the kernels use (for tests / hosts that want to cross-check). */
 int dvo_get_level_intrinsics(const dvo_ctx* ctx, int level, float* k3x4);
@@ -179,9 +180,10 @@ int dvo_solve_batch_fetch(dvo_ctx* ctx, int n_pairs, float* T_out, double* xi_ou
 
 /* Motion prior of the reference (sigma, base_robust_dvo.py:69-71,:154,:190-194,:217-218) for subsequent
  * dvo_solve_batch calls: H += I/sigma, b += (I/sigma) log(old), err += 0.5 sigma |log(old)|, old <- inc^-1 old, with
- * `old` restarting at every level from the previous pair's transform last_qt[pair] = (qw qx qy qz tx ty tz), or the
- * identity when last_qt is NULL.  sigma <= 0 switches the prior off.  The prior couples consecutive pairs of a
- * sequence, so with it a sequence is processed pair after pair (SURVEY 8e "when not"). */
+ * `old` restarting at every level from the previous pair's transform last_qt[pair] = (qw qx qy qz tx ty tz).  With
+ * last_qt == NULL there is no previous transform and the solve applies NO prior, as the reference does for the first
+ * pair of a sequence (`old is None`, base_robust_dvo.py:154,:190).  sigma <= 0 switches the prior off.  The prior couples
+ * consecutive pairs of a sequence, so with it a sequence is processed pair after pair (SURVEY 8e "when not"). */
 int dvo_set_prior(dvo_ctx* ctx, double sigma, const double* last_qt, int n_pairs);
 
 /* Per-iteration trace of dvo_solve_batch (tests / debugging): enable with the number of iterations to keep

@@ -36,7 +36,7 @@ vectorised form accumulates in float64 as numba's type inference does, the inter
 accumulates in float32).
 
 Outputs (tests/golden/): frames.npz (inputs), pairs_l4.npz, single_l1.npz, weighted_l4.npz,
-approx_l4.npz, sigma_l4.npz, dense_rj.npz, tiny10.npz, sequence.npz, lie.npz, meta.json.
+approx_l4.npz, sigma_l4.npz, dense_rj.npz, tiny10.npz, sequence.npz, lie.npz, bilinear_ref.npz, meta.json.
 """
 import json
 import sys
@@ -156,10 +156,47 @@ def _check_vectorised_equivalents(frames, cam):
     return res
 
 
+def _check_bilinear_replacement(frames, cam, lvl=1, n_keep=6000):
+    """The one replaced function against the reference's ORIGINAL `RobustDVOCPU.interpolate_bilinear`
+    (cpu_robust_dense_visual_odometry.py:202-254, run here as plain Python: identity `njit`) on every warped
+    coordinate of pyramid level `lvl` of pair (1,2) that is STRICTLY interior — x0 >= 0, y0 >= 0, x1 < W, y1 < H, i.e.
+    where the original's bounds test (:241) does not fire and the function is well defined — for a uint8 image (the
+    intensity lookup, :175-177) and a float32 plane (the Sobel gradient lookups, :123-128).  Must be bit-identical.
+    The first `n_keep` coordinates with the ORIGINAL function's outputs are written to bilinear_ref.npz so the oracle's
+    own `bilinear` is pinned to the reference function on the GPU box too."""
+    gray1, depth1 = frames[0]
+    gray2, _ = frames[1]
+    d = ImagePyramid(4, depth1).at(lvl)
+    img = ImagePyramid(4, gray2).at(lvl)
+    gx = cv2.Sobel(img, cv2.CV_32F, 1, 0, ksize=3, borderType=cv2.BORDER_REFLECT)
+    pc, _ = cam.deproject(d, return_mask=True, level=lvl)
+    xi = np.array([0.0017, -0.0071, -0.0108, 0.0050, 0.0065, 0.0034], dtype=np.float32).reshape(6, 1)
+    uv = cam.project(np.dot(Se3.from_se3(xi).exp(), pc), level=lvl)[:2, :].T.astype(np.float32)
+    h, w = img.shape
+    x0 = np.floor(uv[:, 0]).astype(np.int64)
+    y0 = np.floor(uv[:, 1]).astype(np.int64)
+    interior = (x0 >= 0) & (y0 >= 0) & (x0 + 1 < w) & (y0 + 1 < h)
+    pts = np.ascontiguousarray(uv[interior])
+    orig = _ORIG["bilinear"]
+    res = {"level": lvl, "points_total": int(uv.shape[0]), "points_strictly_interior": int(pts.shape[0])}
+    outs = {}
+    for name, image in (("u8", img), ("f32", np.ascontiguousarray(gx, dtype=np.float32))):
+        a = orig(image, pts)
+        b = closed_boundary_bilinear(image, pts)
+        assert a.dtype == np.float32 and a.shape == b.shape
+        res[name + "_bit_exact"] = bool(np.array_equal(a, b)) and not bool(np.isnan(a).any())
+        res[name + "_max_abs_diff"] = float(np.max(np.abs(a.astype(np.float64) - b.astype(np.float64))))
+        outs[name] = a
+    np.savez_compressed(OUT / "bilinear_ref.npz", image_u8=img, image_f32=np.ascontiguousarray(gx, dtype=np.float32),
+                        coords=pts[:n_keep], out_u8=outs["u8"][:n_keep], out_f32=outs["f32"][:n_keep])
+    return res
+
+
 def install_patches():
     _ORIG["warp"] = _jac.compute_jacobian_of_warp_function
     _ORIG["fill"] = RobustDVOCPU._fill_jacobian
     _ORIG["scale"] = TDistributionWeighter._compute_scale
+    _ORIG["bilinear"] = RobustDVOCPU.interpolate_bilinear      # the reference's own function, kept for the check above
     RobustDVOCPU.interpolate_bilinear = staticmethod(closed_boundary_bilinear)
 
 
@@ -325,6 +362,9 @@ def main():
 
     meta["vectorised_loop_check"] = _check_vectorised_equivalents(frames, cam)
     print("vectorised loop check:", meta["vectorised_loop_check"], flush=True)
+    meta["bilinear_replacement_check"] = _check_bilinear_replacement(frames, cam)
+    print("bilinear replacement check:", meta["bilinear_replacement_check"], flush=True)
+    assert meta["bilinear_replacement_check"]["u8_bit_exact"] and meta["bilinear_replacement_check"]["f32_bit_exact"]
     install_fast_loops()
 
     K = np.array(cam.intrinsics[:3, :3], dtype=np.float32)

@@ -801,3 +801,129 @@ def test_frames_uploaded_before_the_camera_must_be_uploaded_again(frames):
         ctx.set_camera(K[0, 0] * 1.01, K[1, 1], K[0, 2], K[1, 2], K[0, 1], 2.0 * frames["depth_scale"])   # intrinsics only: lists stay valid
         ctx.upload_frame(0, frames["gray"][0], frames["depth"][0], 2)
         assert ctx.normal_equations(0, [0], [1], T).shape == ref.shape
+
+
+# ------------------------------------------------------------------------------------------------
+# round-2 regressions: graph cache vs camera change, first-pair prior, step_gray guard, factory default
+# ------------------------------------------------------------------------------------------------
+def test_solve_graph_follows_a_camera_change(frames):
+    """dvo_solve_batch replays a captured launch graph; the level intrinsics are kernel arguments inside it.  After
+    dvo_set_camera (same image size, other K — e.g. TUM fr1 then fr2 on one ctx) the next solve must use the new
+    intrinsics: bit-identical to a fresh context, and different from the solve under the old camera."""
+    import dvo_amd
+    K, sc = frames["K"], frames["depth_scale"]
+
+    def solve(ctx):
+        return ctx.solve_batch([0, 1], [1, 2], levels=4, max_iterations=6)
+
+    def load(ctx, fx_scale, skew):
+        ctx.set_camera(K[0, 0] * fx_scale, K[1, 1], K[0, 2], K[1, 2], skew, sc)
+        ctx.upload_frames([0, 1, 2], frames["gray"][:3], frames["depth"][:3], 4)
+
+    with dvo_amd.HipContext(max_w=640, max_h=480, max_levels=4, n_slots=3, max_pairs=2) as ctx:
+        load(ctx, 1.0, 0.0)
+        a = solve(ctx)
+        a2 = solve(ctx)                                   # replayed graph
+        assert np.array_equal(a["xi"], a2["xi"])
+        load(ctx, 1.01, 0.0)
+        b = solve(ctx)
+        load(ctx, 1.01, 0.3)                              # skew switches the kernel instantiation inside the graph
+        c = solve(ctx)
+        ctx.set_camera(K[0, 0] * 1.01, K[1, 1], K[0, 2], K[1, 2], 0.0, sc)     # intrinsics only: no re-upload needed
+        b2 = solve(ctx)
+    fresh = []
+    for fx_scale, skew in ((1.01, 0.0), (1.01, 0.3)):
+        with dvo_amd.HipContext(max_w=640, max_h=480, max_levels=4, n_slots=3, max_pairs=2) as ctx:
+            load(ctx, fx_scale, skew)
+            fresh.append(solve(ctx))
+    assert np.array_equal(b["xi"], fresh[0]["xi"]) and np.array_equal(b["T"], fresh[0]["T"])
+    assert np.array_equal(c["xi"], fresh[1]["xi"])
+    assert np.array_equal(b2["xi"], fresh[0]["xi"])
+    assert np.abs(a["xi"] - b["xi"]).max() > 1e-6 and np.abs(b["xi"] - c["xi"]).max() > 1e-6
+
+
+def test_prior_without_previous_transform_is_no_prior(frames):
+    """First pair of a sequence: `old is None`, the reference applies no prior (base_robust_dvo.py:154,:190).
+    dvo_set_prior(sigma, NULL) through the C ABI must therefore solve exactly like sigma off."""
+    import dvo_amd
+    K = frames["K"]
+    with dvo_amd.HipContext(max_w=640, max_h=480, max_levels=4, n_slots=2, max_pairs=1) as ctx:
+        ctx.set_camera(K[0, 0], K[1, 1], K[0, 2], K[1, 2], K[0, 1], frames["depth_scale"])
+        ctx.upload_frames([0, 1], frames["gray"][:2], frames["depth"][:2], 4)
+        ctx.set_prior(None)
+        a = ctx.solve_batch([0], [1], levels=4, max_iterations=8)
+        ctx.set_prior(1e-13, None)
+        b = ctx.solve_batch([0], [1], levels=4, max_iterations=8)
+        qt = np.array([[1.0, 0, 0, 0, 0, 0, 0]])
+        ctx.set_prior(1e-13, qt)                          # an explicit identity `last` DOES damp the step
+        c = ctx.solve_batch([0], [1], levels=4, max_iterations=8)
+    assert np.array_equal(a["xi"], b["xi"]) and np.array_equal(a["iters"], b["iters"])
+    assert np.abs(a["xi"] - c["xi"]).max() > 1e-5
+
+
+@pytest.mark.parametrize("entry", ["step", "step_gray"])
+def test_step_keeps_state_when_no_transform_is_found(frames, entry, monkeypatch):
+    """core/base_dense_visual_odometry.py:76-87: a `None` transform leaves pose and previous frame untouched and is
+    returned to the caller (both `step` and `step_gray`)."""
+    dvo, dvo_amd = _make_dvo(frames, levels=2, max_iterations=3, solver="device")
+
+    def feed(k):
+        if entry == "step":
+            return dvo.step(np.repeat(frames["gray"][k][..., None], 3, axis=2), frames["depth"][k].copy())
+        return dvo.step_gray(frames["gray"][k], frames["depth"][k])
+
+    feed(0)
+    t1 = feed(1)
+    pose1 = dvo.current_pose.exp().copy()
+    monkeypatch.setattr(dvo, "_gauss_newton", lambda init_guess: None)
+    assert feed(2) is None
+    assert np.array_equal(dvo.current_pose.exp(), pose1)
+    monkeypatch.undo()
+    t3 = feed(2)                                          # still aligned against frame 1 (the failed frame was dropped)
+    ref = O.gauss_newton(frames["gray"][1], frames["depth"][1], frames["gray"][2], frames["K"], frames["depth_scale"],
+                         levels=2, max_iterations=3)
+    np.testing.assert_allclose(t3.log().reshape(6), ref.log(), rtol=0, atol=2e-6)
+    assert t1 is not None
+
+
+def test_factory_accepts_the_reference_default_use_gpu_false(frames):
+    """core/robust_dense_visual_odometry/__init__.py:5: the reference's factory defaults to use_gpu=False; a reference
+    config carrying it must load (the HIP backend reproduces the CPU backend's semantics)."""
+    import dvo_amd
+    cam = dvo_amd.RGBDCameraModel(frames["K"], frames["depth_scale"])
+    a = dvo_amd.get_dvo("robust-dvo", cam, dvo_amd.Se3.identity(), levels=1, use_gpu=False, height=48, width=64)
+    b = dvo_amd.get_dvo("robust-dvo", cam, dvo_amd.Se3.identity(), levels=1, height=48, width=64)
+    assert type(a) is type(b) is dvo_amd.RobustDVOHIP
+    with pytest.raises(ValueError):
+        dvo_amd.get_dvo("robust-dvo", cam, dvo_amd.Se3.identity(), levels=1, backend="cuda")
+
+
+# ------------------------------------------------------------------------------------------------
+# BASELINE config 3 at full size against the oracle (not only through properties)
+# ------------------------------------------------------------------------------------------------
+def test_config3_1280x960_normal_equations_vs_oracle():
+    """1280x960, 5-level pyramid: the fused reduction at the finest and the coarsest level, unweighted and Huber,
+    against oracle.residuals_and_jacobian + normal_equations on the same seeded synthetic pair (N exact, H / b /
+    increment tolerances as at VGA)."""
+    import dvo_amd
+    from dvo_amd import synthetic, _cabi
+    st = synthetic.make_stream(2, 1280, 960, seed=5, device="cuda")
+    K, sc = np.asarray(st["K"], dtype=np.float32), st["depth_scale"]
+    g, d = st["gray"], st["depth"]
+    gp, dp, gc = O.build_pyramid(g[0], 5), O.build_pyramid(d[0], 5), O.build_pyramid(g[1], 5)
+    T = O.Pose.from_xi(np.array([0.004, -0.003, 0.006, 0.003, -0.002, 0.0015])).matrix()
+    with dvo_amd.HipContext(max_w=1280, max_h=960, max_levels=5, n_slots=2, max_pairs=1) as ctx:
+        ctx.set_camera(K[0, 0], K[1, 1], K[0, 2], K[1, 2], K[0, 1], sc)
+        ctx.upload_frames([0, 1], g[:2], d[:2], 5)
+        for lvl in (0, 4):
+            lv = O.PairLevel(gp[lvl], dp[lvl], gc[lvl], O.level_intrinsics(K, lvl), sc)
+            r, J, _, _ = O.residuals_and_jacobian(lv, T)
+            k = 1.345 * float(np.sqrt(np.mean(r.astype(np.float64) ** 2)))
+            for mode, par, w in ((_cabi.WEIGHT_NONE, None, None),
+                                 (_cabi.WEIGHT_HUBER, [k], O.huber_weights(r, float(np.float32(k))))):
+                rec = ctx.normal_equations(lvl, [0], [1], T[None], _cabi.VARIANT_V1, mode, par)[0]
+                H, b, swr2, n, _ = _cabi.unpack_record(rec)
+                Ho, bo, so, no = O.normal_equations(r, J, w)
+                assert n == no and n > (300_000 if lvl == 0 else 1_000)
+                assert _rel(H, Ho) < 1e-6 and _rel(b, bo) < 2e-6 and abs(swr2 - so) < 2e-6 * so
+                assert _rel(_solve(H, b), O.solve_increment(Ho, bo)) < 1e-5

@@ -35,21 +35,38 @@ def main():
     ap.add_argument("--window", type=int, default=128, help="frames per batched solve")
     ap.add_argument("--camera", type=Path, default=None, help="camera_intrinsics.yaml (TUM mode; default fr1)")
     ap.add_argument("--out", type=Path, default=ROOT / "gpurun_out" / "sequence")
+    ap.add_argument("--gpus", type=int, default=1, help="shard the pairs of the sequence over this many GPUs (one process each)")
+    ap.add_argument("--spawn", action="store_true", help="go through the rank launcher even for --gpus 1")
     args = ap.parse_args()
+
+    from dvo_amd import launch
+    # BASELINE config 4: one process per GPU; `--gpus N` starts its own ranks (fresh children, before any HIP call in
+    # this process) unless a launcher (torchrun) already did.  The pairs of the sequence are split into contiguous
+    # ranges, one per rank; the pose records are all-gathered over RCCL and rank 0 composes / writes the trajectory.
+    if not launch.started_by_launcher() and (args.gpus > 1 or args.spawn):
+        try:
+            raise SystemExit(launch.launch_ranks(args.gpus, str(Path(__file__).resolve()), [a for a in sys.argv[1:] if a != "--spawn"]))
+        except launch.LaunchError as e:
+            raise SystemExit("run_sequence.py: %s" % e)
 
     from dvo_amd import synthetic, tum, RGBDCameraModel
     from dvo_amd.batch import BatchAligner, compose_trajectory, shard_pairs, pose_records, allgather_poses
 
-    # BASELINE config 4: under torchrun (one process per GPU) the pairs of the sequence are split into contiguous
-    # ranges, one per rank; the pose records are all-gathered over RCCL and rank 0 composes / writes the trajectory.
     import os
-    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1 or os.environ.get("DVO_FORCE_DIST") == "1":
+    rank, local_rank, world = launch.rank_env()
+    use_dist = launch.started_by_launcher() or os.environ.get("DVO_FORCE_DIST") == "1"
+    if use_dist:
+        try:
+            launch.check_world(args.gpus)
+        except launch.LaunchError as e:
+            raise SystemExit("run_sequence.py: %s" % e)
         import torch
         import torch.distributed as dist
+        if local_rank >= torch.cuda.device_count():
+            raise SystemExit("run_sequence.py: rank %d has no GPU" % rank)
         torch.cuda.set_device(local_rank)
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        world = dist.get_world_size()
 
     gray_mode = True
     if args.fixture:
@@ -69,7 +86,7 @@ def main():
         frames, gt, stamps, kind, gray_mode = tum.iter_frames(seq), seq.gt_T_wc, seq.timestamps, "TUM", False
 
     n_total = None
-    if world > 1 or os.environ.get("DVO_FORCE_DIST") == "1":
+    if use_dist:
         frames = list(frames)                      # (a rank only needs its own range; kept simple here)
         n_total = len(frames)
         lo, hi = shard_pairs(n_total - 1, rank, world)
