@@ -116,6 +116,40 @@ struct DvoSolveParams {
     int trace_stride, trace_cap;
 };
 
+// Persistent small-level Gauss-Newton kernel (k_gn_small): ONE workgroup per frame pair runs every iteration of up to
+// DVO_SMALL_LEVELS consecutive coarse pyramid levels — reduction, 6x6 solve, SE(3) update and stop rules — without
+// leaving the kernel (no launch per iteration, no partial sums through HBM).
+#define DVO_SMALL_LEVELS 4
+struct DvoSmallParams {
+    const uint8_t* slots;
+    size_t slot_stride;
+    const int* prev_slot;
+    const int* cur_slot;
+    const int* list_count;       // [n_slots][DVO_LIST_LEVELS]
+    int n_levels;                // levels handled by this launch, coarse to fine: level_id[0] > level_id[1] > ...
+    int level_id[DVO_SMALL_LEVELS];
+    DvoLevelGeom g[DVO_SMALL_LEVELS];
+    DvoLevelCam cam[DVO_SMALL_LEVELS];
+    double depth_scale;
+    int n_pairs;
+    int max_iterations;
+    DvoPairState* state;         // [n_pairs]
+    float* T;                    // [n_pairs][12]
+    int* active;                 // [n_pairs]
+    double* wparam;              // [n_pairs]
+    float* rcache;               // Student-t: [n_pairs][rcache_stride] residuals of the current pose, or null (recompute)
+    size_t rcache_stride;
+    double tolerance;
+    int max_increased;
+    int weight_mode;
+    double weight_param;
+    double inv_sigma;
+    double lambda0;              // Student-t: 1 / initial_sigma^2
+    int student_t_mean;          // Student-t scale = mean (proper) instead of the reference's sum (quirk Q3)
+    double* trace;
+    int trace_stride, trace_cap;
+};
+
 struct DvoBatchIngestParams {
     uint8_t* slots;
     size_t slot_stride;
@@ -144,6 +178,7 @@ hipError_t dvo_launch_init_state(DvoPairState* st, float* T, const float* T_init
 hipError_t dvo_launch_level_begin(DvoPairState* st, int* active, double* wparam, int n_pairs, int weight_mode,
                                   double lambda0, hipStream_t s);
 hipError_t dvo_launch_solve(const DvoSolveParams& p, hipStream_t s);
+hipError_t dvo_launch_gn_small(const DvoSmallParams& p, int variant, int threads, hipStream_t s);
 hipError_t dvo_launch_debug_divide(const float* a, const float* b, float* out, float* ref, int n, hipStream_t s);
 hipError_t dvo_launch_finish(const DvoPairState* st, int n_pairs, double* xi_out, int* iters_out, double* err_out,
                              hipStream_t s);

@@ -1501,17 +1501,19 @@ hipError_t dvo_launch_level_begin(DvoPairState* st, int* active, double* wparam,
 
 // Scalar control of one Gauss-Newton iteration of one pair (run by ONE thread): base_robust_dvo.py:166-232.
 // `rec` is the summed normal-equation record (modified in place when the motion prior is on).
-__device__ __forceinline__ void gn_control(const DvoSolveParams& p, int pair, double* rec)
+// P supplies the scalars (tolerance, max_increased, weight_mode, weight_param, inv_sigma, trace*): DvoSolveParams (k_solve:
+// state / T / active / wparam in global memory) or DvoSmallParams (k_gn_small: the same objects held in LDS).
+template <class P>
+__device__ __forceinline__ void gn_control(const P& p, int phase, int pair, DvoPairState& st, float* T, int* active,
+                                           double* wparam, double* rec)
 {
-    DvoPairState& st = p.state[pair];
-
-    if (p.phase != 0) {
+    if (phase != 0) {
         // Student-t scale pass k (weighter/t_weighter.py:24-32): lambda <- 1 / sum, stop when |d lambda| < 1e-3
-        const double last = p.wparam[pair];
+        const double last = *wparam;
         if (st.pad == 0) {                       // pad: 1 once the IRLS loop has converged for this iteration
             const double cur = 1.0 / rec[0];
             if (fabs(cur - last) < 1e-3) st.pad = 1;
-            p.wparam[pair] = cur;
+            *wparam = cur;
         }
         return;
     }
@@ -1536,7 +1538,7 @@ __device__ __forceinline__ void gn_control(const DvoSolveParams& p, int pair, do
         double* tr = p.trace + ((size_t)pair * p.trace_cap + (st.iters - 1)) * p.trace_stride;
         for (int i = 0; i < DVO_STRIDE; ++i) tr[i] = rec[i];
         for (int i = 0; i < 6; ++i) tr[DVO_STRIDE + i] = inc[i];
-        for (int i = 0; i < 12; ++i) tr[DVO_STRIDE + 6 + i] = (double)p.T[(size_t)pair * 12 + i];
+        for (int i = 0; i < 12; ++i) tr[DVO_STRIDE + 6 + i] = (double)T[i];
     }
     const double diff = err - st.err_prev;
     bool stop = false;
@@ -1551,7 +1553,7 @@ __device__ __forceinline__ void gn_control(const DvoSolveParams& p, int pair, do
             for (int i = 0; i < 3; ++i) st.t[i] = tn[i];
             st.err_prev = err;
             st.increased = 0;
-            se3_write_T(st.q, st.t, p.T + (size_t)pair * 12);
+            se3_write_T(st.q, st.t, T);
             if (p.inv_sigma > 0.0) {                                                    // old = inc.inverse() * old  (:217-218)
                 double qv[4] = {qi[0], -qi[1], -qi[2], -qi[3]}, Ri[9], tv[3], qo[4], to[3];
                 quat_to_R(qv, Ri);
@@ -1565,29 +1567,63 @@ __device__ __forceinline__ void gn_control(const DvoSolveParams& p, int pair, do
         }
         if (st.increased > p.max_increased) stop = true;                                // :224
     }
-    if (stop) { st.active = 0; p.active[pair] = 0; }
-    if (p.weight_mode == 1) { p.wparam[pair] = 1.0 / 25.0; st.pad = 0; }                // next iteration restarts IRLS
+    if (stop) { st.active = 0; *active = 0; }
+    if (p.weight_mode == 1) { *wparam = 1.0 / 25.0; st.pad = 0; }                       // next iteration restarts IRLS
     if (p.weight_mode == 2) {
         const double sig = (n > 0.0) ? sqrt(rec[29] / n) : -1.0;
         st.lambda = (sig > 0.0) ? p.weight_param * sig : -1.0;
-        p.wparam[pair] = (st.lambda > 0.0) ? st.lambda : DVO_FLT_MAX;
+        *wparam = (st.lambda > 0.0) ? st.lambda : DVO_FLT_MAX;
     }
 }
 
-// One workgroup per pair: sum partials, then lane 0 runs the scalar control of one GN iteration.
-__global__ __launch_bounds__(DVO_BLOCK) void k_solve(const DvoSolveParams p)
+// One WAVE per pair: the 64 lanes sum the pair's per-workgroup partials (same fixed order as sum_partials_block: eight
+// interleaved running sums per column, then those in order, so the record is bit-identical to k_sum_partials'), then
+// lane 0 runs the scalar control of one GN iteration.  A 64-thread workgroup occupies one SIMD slot instead of a whole CU
+// (the control code is a one-lane float64 program at 1 wave/SIMD): the reductions of other streams keep running beside it.
+__global__ __launch_bounds__(64) void k_solve(const DvoSolveParams p)
 {
     const int pair = blockIdx.x;
     if (p.active[pair] == 0) return;
     __shared__ double rec[DVO_STRIDE];
-    sum_partials_block(p.partials + (size_t)pair * p.blocks_per_pair * DVO_STRIDE, p.blocks_per_pair, rec);
+    __shared__ double tmp[8][DVO_STRIDE];
+    {
+        const double* __restrict__ part = p.partials + (size_t)pair * p.blocks_per_pair * DVO_STRIDE;
+        const int c = threadIdx.x & 31, h = threadIdx.x >> 5;
+        // lane (c, h) keeps the running sums g = h, h+2, h+4, h+6 of column c; the loads of two rounds (8 per lane) are
+        // issued before the first add, each sum still adds its terms in increasing b
+        double s4[4] = {0.0, 0.0, 0.0, 0.0};
+        const int nblk = p.blocks_per_pair;
+        for (int b0 = 0; b0 < nblk; b0 += 16) {
+            double x[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int b = b0 + (q >> 2) * 8 + h + 2 * (q & 3);
+                x[q] = (b < nblk) ? part[(size_t)b * DVO_STRIDE + c] : 0.0;
+            }
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int b = b0 + (q >> 2) * 8 + h + 2 * (q & 3);
+                if (b < nblk) s4[q & 3] += x[q];
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) tmp[h + 2 * q][c] = s4[q];
+        __syncthreads();
+        if (threadIdx.x < DVO_STRIDE) {
+            double t = 0.0;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) t += tmp[k][threadIdx.x];
+            rec[threadIdx.x] = t;
+        }
+        __syncthreads();
+    }
     if (threadIdx.x != 0) return;
-    gn_control(p, pair, rec);
+    gn_control(p, p.phase, pair, p.state[pair], p.T + (size_t)pair * 12, p.active + pair, p.wparam + pair, rec);
 }
 
 hipError_t dvo_launch_solve(const DvoSolveParams& p, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_solve, dim3(p.n_pairs), dim3(DVO_BLOCK), 0, s, p);
+    hipLaunchKernelGGL(k_solve, dim3(p.n_pairs), dim3(64), 0, s, p);
     return hipGetLastError();
 }
 
