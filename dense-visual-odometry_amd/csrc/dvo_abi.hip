@@ -124,7 +124,9 @@ struct dvo_ctx {
         bool st_solve_phases = false;   // DVO_ST_SOLVE_PHASES: Student-t device solve with control launches between the passes
         bool no_rcache = false;         // DVO_NO_RCACHE: second Student-t scale pass recomputes the residuals
         bool ingest_unfused = false;    // DVO_INGEST_UNFUSED: separate ingest kernels for every level (tests)
-        bool fused_solve = true;        // DVO_FUSED_SOLVE=0: control step as its own launch (k_solve) instead of in k_reduce
+        int small_max_pix = 19200;      // DVO_SMALL_MAX_PIX: levels with at most this many pixels run in the persistent per-pair
+                                        // kernel k_gn_small (0: every level takes the per-iteration launches)
+        int small_threads = 0;          // DVO_SMALL_THREADS: workgroup size of k_gn_small (0: chosen from the batch size)
     } knobs;
     char err[512] = "";
 };
@@ -478,8 +480,10 @@ int dvo_create(int device, int max_w, int max_h, int max_levels, int n_slots, in
         ctx->knobs.st_solve_phases = getenv("DVO_ST_SOLVE_PHASES") != nullptr;
         ctx->knobs.no_rcache = getenv("DVO_NO_RCACHE") != nullptr;
         ctx->knobs.ingest_unfused = getenv("DVO_INGEST_UNFUSED") != nullptr;
-        e = getenv("DVO_FUSED_SOLVE");
-        ctx->knobs.fused_solve = !(e && e[0] == '0');
+        e = getenv("DVO_SMALL_MAX_PIX");
+        if (e) ctx->knobs.small_max_pix = atoi(e);
+        e = getenv("DVO_SMALL_THREADS");
+        if (e && (atoi(e) == 256 || atoi(e) == 512 || atoi(e) == 1024)) ctx->knobs.small_threads = atoi(e);
     }
 #undef CREATE_TRY
     *out = ctx;
@@ -934,7 +938,66 @@ static int record_solve(dvo_ctx* ctx, const SolveKey& k, const float* d_init)
     const double lambda0 = 1.0 / 25.0;                      // TDistributionWeighter: initial_sigma = 5 (t_weighter.py:11-15)
     HIP_TRY(ctx, dvo_launch_init_state(ctx->d_state, ctx->d_T, d_init, n_pairs, lambda0,
                                        (k.inv_sigma > 0.0 && k.has_last) ? ctx->d_prior : nullptr, ctx->stream));
-    for (int level = levels - 1; level >= 0; --level) {
+    // The coarsest levels (at most knobs.small_max_pix pixels each) run in ONE persistent launch, a workgroup per pair
+    // doing every iteration of those levels (k_gn_small); the finer levels take one reduction launch + one control launch
+    // per iteration.
+    int level = levels - 1;
+    if (variant != DVO_VARIANT_V3 && max_iterations > 0) {
+        DvoLevelGeom g[DVO_MAX_LEVELS];
+        level_geometry(w, h, levels, g, nullptr);
+        DvoSmallParams sp;
+        memset(&sp, 0, sizeof(sp));
+        int n = 0;
+        while (level - n >= 0 && n < DVO_SMALL_LEVELS && g[level - n].npix <= ctx->knobs.small_max_pix) {
+            sp.level_id[n] = level - n;
+            sp.g[n] = g[level - n];
+            sp.cam[n] = level_camera(ctx, level - n);
+            ++n;
+        }
+        if (n > 0) {
+            sp.slots = ctx->d_slots;
+            sp.slot_stride = ctx->slot_stride;
+            sp.prev_slot = ctx->d_prev;
+            sp.cur_slot = ctx->d_cur;
+            sp.list_count = ctx->d_list_count;
+            sp.n_levels = n;
+            sp.depth_scale = ctx->depth_scale;
+            sp.n_pairs = n_pairs;
+            sp.max_iterations = max_iterations;
+            sp.state = ctx->d_state;
+            sp.T = ctx->d_T;
+            sp.active = ctx->d_active;
+            sp.wparam = ctx->d_wparam;
+            sp.rcache = (weight_mode == DVO_WEIGHT_STUDENT_T) ? ctx->d_rcache : nullptr;
+            sp.rcache_stride = (size_t)ctx->max_w * ctx->max_h;
+            sp.tolerance = tolerance;
+            sp.max_increased = max_increased_steps_allowed;
+            sp.weight_mode = weight_mode;
+            sp.weight_param = weight_param;
+            sp.inv_sigma = k.has_last ? k.inv_sigma : 0.0;
+            sp.lambda0 = lambda0;
+            sp.trace = ctx->d_trace;
+            sp.trace_stride = DVO_STRIDE + 18;
+            sp.trace_cap = ctx->trace_cap;
+            // workgroup size: the whole batch should be resident at once (<= 2048 threads per CU at <= 128 VGPRs); a single
+            // pair gets the widest workgroup (latency), a large batch narrower ones (more pairs in flight per CU)
+            int threads = ctx->knobs.small_threads;
+            if (threads == 0) threads = (n_pairs <= 8) ? 1024 : (n_pairs <= 64) ? 512 : 256;   // measured: B=256 per stream: 256 > 512 > 1024
+            hipEvent_t ea = nullptr, eb = nullptr;
+            if (ctx->profiling) {
+                ea = pool_event(ctx);
+                eb = pool_event(ctx);
+                if (ea && eb) (void)hipEventRecord(ea, ctx->stream);
+            }
+            HIP_TRY(ctx, dvo_launch_gn_small(sp, variant, threads, ctx->stream));
+            if (ctx->profiling && ea && eb) {
+                (void)hipEventRecord(eb, ctx->stream);
+                ctx->pending.push_back({ea, eb, level});        // booked on the coarsest level it covers
+            }
+            level -= n;
+        }
+    }
+    for (; level >= 0; --level) {
         DvoReduceParams p;
         rc = fill_reduce_params(ctx, level, n_pairs, w, h, &p);
         if (rc) return rc;

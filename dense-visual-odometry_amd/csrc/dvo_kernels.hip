@@ -1230,6 +1230,18 @@ __device__ inline void quat_log(const double* q, double* phi)
     phi[0] = theta * q[1]; phi[1] = theta * q[2]; phi[2] = theta * q[3];
 }
 
+// 1 / x for a float64 x in the normal range: v_rcp_f64 (about 26 good bits) + two Newton steps, about 1 ulp.  The control
+// step is ONE lane's serial float64 program and its time is its instruction count (a lone wave issues one instruction
+// every few cycles): the compiler's IEEE division is ~15 instructions and a float64 sqrt ~30, this is 5.
+__device__ __forceinline__ double rcp64(double x)
+{
+    double r = __builtin_amdgcn_rcp(x);
+    double e = fma(-x, r, 1.0);
+    r = fma(e, r, r);
+    e = fma(-x, r, 1.0);
+    return fma(e, r, r);
+}
+
 // Se3.from_se3 (special_euclidean_group.py:105-123): xi = (upsilon, omega) -> (q, t = V upsilon)
 __device__ inline void se3_from_xi(const double* xi, double* q, double* t)
 {
@@ -1240,19 +1252,28 @@ __device__ inline void se3_from_xi(const double* xi, double* q, double* t)
         t[0] = xi[0]; t[1] = xi[1]; t[2] = xi[2];
         return;
     }
-    const double ax = ox / theta, ay = oy / theta, az = oz / theta;
-    theta = wrap_angle_d(theta);                                   // So3.__init__ :46-50
-    double px = theta * ax, py = theta * ay, pz = theta * az;
-    const double th = sqrt(px * px + py * py + pz * pz);
-    if (th < DVO_LIE_EPS) {                                        // wrapped to ~0: So3.log would return 0
-        q[0] = 1; q[1] = q[2] = q[3] = 0;
-        t[0] = xi[0]; t[1] = xi[1]; t[2] = xi[2];
-        return;
+    double px = ox, py = oy, pz = oz, th = theta;
+    if (!(theta < 3.0)) {
+        // angles near or beyond pi: So3.__init__ wraps theta (:46-50) and rebuilds phi from the unit axis.  Below 3 rad the
+        // wrap is the identity up to the rounding of (theta + pi) - pi, and phi = omega.
+        const double ax = ox / theta, ay = oy / theta, az = oz / theta;
+        theta = wrap_angle_d(theta);
+        px = theta * ax; py = theta * ay; pz = theta * az;
+        th = sqrt(px * px + py * py + pz * pz);
+        if (th < DVO_LIE_EPS) {                                    // wrapped to ~0: So3.log would return 0
+            q[0] = 1; q[1] = q[2] = q[3] = 0;
+            t[0] = xi[0]; t[1] = xi[1]; t[2] = xi[2];
+            return;
+        }
     }
-    const double s2 = sin(th * 0.5), c2 = cos(th * 0.5);
-    q[0] = c2; q[1] = s2 * px / th; q[2] = s2 * py / th; q[3] = s2 * pz / th;
-    // V = I + (1-cos)/th^2 [phi]x + (th - sin)/th^3 [phi]x^2
-    const double A = (1.0 - cos(th)) / (th * th), B = (th - sin(th)) / (th * th * th);
+    double s2, c2;
+    sincos(th * 0.5, &s2, &c2);
+    const double rth = rcp64(th);
+    const double k = s2 * rth;
+    q[0] = c2; q[1] = k * px; q[2] = k * py; q[3] = k * pz;
+    // V = I + (1-cos)/th^2 [phi]x + (th - sin)/th^3 [phi]x^2, with 1 - cos th = 2 sin^2(th/2), sin th = 2 sin(th/2) cos(th/2)
+    const double rth2 = rth * rth;
+    const double A = 2.0 * s2 * s2 * rth2, B = (th - 2.0 * s2 * c2) * (rth2 * rth);
     const double ux = xi[0], uy = xi[1], uz = xi[2];
     const double c1x = py * uz - pz * uy, c1y = pz * ux - px * uz, c1z = px * uy - py * ux;          // phi x u
     const double c2x = py * c1z - pz * c1y, c2y = pz * c1x - px * c1z, c2z = px * c1y - py * c1x;    // phi x (phi x u)
@@ -1280,10 +1301,18 @@ __device__ inline void se3_mul(const double* qa, const double* ta, const double*
 // Se3.exp (special_euclidean_group.py:35-52): rotation block is the identity when |log| < eps
 __device__ inline void se3_write_T(const double* q, const double* t, float* T)
 {
-    double phi[3], R[9];
-    quat_log(q, phi);
-    const double theta = sqrt(phi[0] * phi[0] + phi[1] * phi[1] + phi[2] * phi[2]);
-    if (theta < DVO_LIE_EPS) { R[0] = R[4] = R[8] = 1; R[1] = R[2] = R[3] = R[5] = R[6] = R[7] = 0; }
+    double R[9];
+    bool ident;
+    if (q[0] > 0.5) {
+        // rotation below 120 degrees (always, between consecutive frames): |log q| = 2 asin(n) >= 2 n with n = |q_xyz|, and
+        // So3.log returns 0 for n < eps — so |log| < eps <=> n < eps, without the atan2 of So3.log
+        ident = (q[1] * q[1] + q[2] * q[2] + q[3] * q[3]) < DVO_LIE_EPS * DVO_LIE_EPS;
+    } else {
+        double phi[3];
+        quat_log(q, phi);
+        ident = sqrt(phi[0] * phi[0] + phi[1] * phi[1] + phi[2] * phi[2]) < DVO_LIE_EPS;
+    }
+    if (ident) { R[0] = R[4] = R[8] = 1; R[1] = R[2] = R[3] = R[5] = R[6] = R[7] = 0; }
     else quat_to_R(q, R);
     T[0] = (float)R[0]; T[1] = (float)R[1]; T[2] = (float)R[2];  T[3] = (float)t[0];
     T[4] = (float)R[3]; T[5] = (float)R[4]; T[6] = (float)R[5];  T[7] = (float)t[1];
@@ -1314,61 +1343,89 @@ __device__ inline void se3_log(const double* q, const double* t, double* xi)
 // Rare path: kept out of line so its runtime-indexed arrays do not push the common path into scratch.
 __device__ __noinline__ void solve6_pinv(const double* hu, const double* b, double dmax, double* x)
 {
+    // every loop is kept rolled (#pragma unroll 1): A and V then stay runtime-indexed arrays in scratch and the function needs
+    // a dozen registers; unrolled, the compiler promotes both matrices to registers (128 VGPRs + spills), and a callee's
+    // registers count against every kernel that can reach it
     double A[6][6], V[6][6];
     {
         int q = 0;
-        for (int i = 0; i < 6; ++i) for (int j = i; j < 6; ++j) { A[i][j] = hu[q]; A[j][i] = hu[q]; ++q; }
+#pragma unroll 1
+        for (int i = 0; i < 6; ++i) {
+#pragma unroll 1
+            for (int j = i; j < 6; ++j) { A[i][j] = hu[q]; A[j][i] = hu[q]; ++q; }
+        }
     }
-    for (int i = 0; i < 6; ++i) for (int j = 0; j < 6; ++j) V[i][j] = (i == j) ? 1.0 : 0.0;
+#pragma unroll 1
+    for (int i = 0; i < 6; ++i) {
+#pragma unroll 1
+        for (int j = 0; j < 6; ++j) V[i][j] = (i == j) ? 1.0 : 0.0;
+    }
+#pragma unroll 1
     for (int sweep = 0; sweep < 30; ++sweep) {
         double off = 0.0;
-        for (int i = 0; i < 6; ++i) for (int j = i + 1; j < 6; ++j) off += A[i][j] * A[i][j];
+#pragma unroll 1
+        for (int i = 0; i < 6; ++i) {
+#pragma unroll 1
+            for (int j = i + 1; j < 6; ++j) off += A[i][j] * A[i][j];
+        }
         if (off <= 1e-60 * dmax * dmax || off == 0.0) break;
-        for (int p = 0; p < 5; ++p) for (int q = p + 1; q < 6; ++q) {
-            if (A[p][q] == 0.0) continue;
-            const double th = (A[q][q] - A[p][p]) / (2.0 * A[p][q]);
-            const double tt = (th >= 0 ? 1.0 : -1.0) / (fabs(th) + sqrt(th * th + 1.0));
-            const double c = 1.0 / sqrt(tt * tt + 1.0), sn = tt * c;
-            for (int k = 0; k < 6; ++k) { const double akp = A[k][p], akq = A[k][q]; A[k][p] = c * akp - sn * akq; A[k][q] = sn * akp + c * akq; }
-            for (int k = 0; k < 6; ++k) { const double apk = A[p][k], aqk = A[q][k]; A[p][k] = c * apk - sn * aqk; A[q][k] = sn * apk + c * aqk; }
-            for (int k = 0; k < 6; ++k) { const double vkp = V[k][p], vkq = V[k][q]; V[k][p] = c * vkp - sn * vkq; V[k][q] = sn * vkp + c * vkq; }
+#pragma unroll 1
+        for (int p = 0; p < 5; ++p) {
+#pragma unroll 1
+            for (int q = p + 1; q < 6; ++q) {
+                if (A[p][q] == 0.0) continue;
+                const double th = (A[q][q] - A[p][p]) / (2.0 * A[p][q]);
+                const double tt = (th >= 0 ? 1.0 : -1.0) / (fabs(th) + sqrt(th * th + 1.0));
+                const double c = 1.0 / sqrt(tt * tt + 1.0), sn = tt * c;
+#pragma unroll 1
+                for (int k = 0; k < 6; ++k) { const double akp = A[k][p], akq = A[k][q]; A[k][p] = c * akp - sn * akq; A[k][q] = sn * akp + c * akq; }
+#pragma unroll 1
+                for (int k = 0; k < 6; ++k) { const double apk = A[p][k], aqk = A[q][k]; A[p][k] = c * apk - sn * aqk; A[q][k] = sn * apk + c * aqk; }
+#pragma unroll 1
+                for (int k = 0; k < 6; ++k) { const double vkp = V[k][p], vkq = V[k][q]; V[k][p] = c * vkp - sn * vkq; V[k][q] = sn * vkp + c * vkq; }
+            }
         }
     }
     double emax = 0.0;
+#pragma unroll 1
     for (int i = 0; i < 6; ++i) emax = fmax(emax, fabs(A[i][i]));
+#pragma unroll 1
     for (int i = 0; i < 6; ++i) x[i] = 0.0;
+#pragma unroll 1
     for (int k = 0; k < 6; ++k) {
         const double e = A[k][k];
         if (fabs(e) <= 2.220446049250313e-16 * emax) continue;
         double vb = 0.0;
+#pragma unroll 1
         for (int i = 0; i < 6; ++i) vb += V[i][k] * b[i];
         vb /= e;
+#pragma unroll 1
         for (int i = 0; i < 6; ++i) x[i] += V[i][k] * vb;
     }
 }
 
 // Solves H x = b for the symmetric positive semi-definite 6x6 H (upper triangle hu[21], row-major).
-// Fast path: fully unrolled Cholesky held in registers; falls back to solve6_pinv when a pivot is not safely
-// positive.
+// Fast path: fully unrolled LDL^T IN PLACE on the 21 packed entries (unit-lower L overwrites the triangle, d the diagonal):
+// no square roots, one Newton reciprocal per pivot, substitutions by multiplication — ~150 float64 instructions instead of
+// the ~800 of a Cholesky with IEEE sqrt and divisions (the pivots are the same numbers: d_j = l_jj^2).  Falls back to
+// solve6_pinv when a pivot is not safely positive (the minimum-norm answer gelsy gives, base_robust_dvo.py:196-198).
+// lo6(i, j), i >= j: position of element (i, j) of the lower triangle = position of (j, i) in the row-major upper triangle.
+__device__ __forceinline__ constexpr int lo6(int i, int j) { return j * 6 - (j * (j - 1)) / 2 + (i - j); }
+
 __device__ __forceinline__ void solve6(const double* hu, const double* b, double* x)
 {
-    double A[6][6];
-    {
-        int q = 0;
+    double a[21];
 #pragma unroll
-        for (int i = 0; i < 6; ++i)
-#pragma unroll
-            for (int j = i; j < 6; ++j) { A[i][j] = hu[q]; A[j][i] = hu[q]; ++q; }
-    }
+    for (int q = 0; q < 21; ++q) a[q] = hu[q];
     bool finite = true;
     double dmax = 0.0;
 #pragma unroll
     for (int i = 0; i < 6; ++i) {
-        dmax = fmax(dmax, fabs(A[i][i]));
+        dmax = fmax(dmax, fabs(a[lo6(i, i)]));
         finite = finite && isfinite(b[i]);
-#pragma unroll
-        for (int j = i; j < 6; ++j) finite = finite && isfinite(A[i][j]);
     }
+#pragma unroll
+    for (int q = 0; q < 21; ++q) finite = finite && isfinite(a[q]);
     if (!finite) {
 #pragma unroll
         for (int i = 0; i < 6; ++i) x[i] = __builtin_nan("");
@@ -1379,40 +1436,46 @@ __device__ __forceinline__ void solve6(const double* hu, const double* b, double
         for (int i = 0; i < 6; ++i) x[i] = 0.0;
         return;
     }
-    double L[6][6];
     bool ok = true;
+    double rd[6];                                            // 1 / d_j
+    const double dmin = 1e-13 * dmax;
 #pragma unroll
     for (int j = 0; j < 6; ++j) {
-        double d = A[j][j];
+        double v[6];                                         // v_k = L_jk d_k
+        double d = a[lo6(j, j)];
 #pragma unroll
-        for (int k = 0; k < j; ++k) d -= L[j][k] * L[j][k];
-        ok = ok && (d > 1e-13 * dmax);
-        const double lj = sqrt(ok ? d : 1.0);
-        const double ilj = 1.0 / lj;
-        L[j][j] = lj;
+        for (int k = 0; k < j; ++k) {
+            v[k] = a[lo6(j, k)] * a[lo6(k, k)];
+            d = fma(-a[lo6(j, k)], v[k], d);
+        }
+        ok = ok && (d > dmin);
+        d = ok ? d : 1.0;
+        a[lo6(j, j)] = d;
+        rd[j] = rcp64(d);
 #pragma unroll
         for (int i = j + 1; i < 6; ++i) {
-            double sacc = A[i][j];
+            double sacc = a[lo6(i, j)];
 #pragma unroll
-            for (int k = 0; k < j; ++k) sacc -= L[i][k] * L[j][k];
-            L[i][j] = sacc * ilj;
+            for (int k = 0; k < j; ++k) sacc = fma(-a[lo6(i, k)], v[k], sacc);
+            a[lo6(i, j)] = sacc * rd[j];
         }
     }
     if (ok) {
-        double y[6];
 #pragma unroll
-        for (int i = 0; i < 6; ++i) {
+        for (int i = 0; i < 6; ++i) {                       // L z = b
             double sacc = b[i];
 #pragma unroll
-            for (int k = 0; k < i; ++k) sacc -= L[i][k] * y[k];
-            y[i] = sacc / L[i][i];
+            for (int k = 0; k < i; ++k) sacc = fma(-a[lo6(i, k)], x[k], sacc);
+            x[i] = sacc;
         }
 #pragma unroll
-        for (int i = 5; i >= 0; --i) {
-            double sacc = y[i];
+        for (int i = 0; i < 6; ++i) x[i] *= rd[i];           // D w = z
 #pragma unroll
-            for (int k = i + 1; k < 6; ++k) sacc -= L[k][i] * x[k];
-            x[i] = sacc / L[i][i];
+        for (int i = 5; i >= 0; --i) {                      // L^T x = w
+            double sacc = x[i];
+#pragma unroll
+            for (int k = i + 1; k < 6; ++k) sacc = fma(-a[lo6(k, i)], x[k], sacc);
+            x[i] = sacc;
         }
         return;
     }
@@ -1624,6 +1687,245 @@ __global__ __launch_bounds__(64) void k_solve(const DvoSolveParams p)
 hipError_t dvo_launch_solve(const DvoSolveParams& p, hipStream_t s)
 {
     hipLaunchKernelGGL(k_solve, dim3(p.n_pairs), dim3(64), 0, s, p);
+    return hipGetLastError();
+}
+
+// ================================================================================================
+// k_gn_small: persistent per-pair Gauss-Newton kernel for the small pyramid levels
+// ================================================================================================
+// One workgroup per frame pair runs EVERY iteration of up to DVO_SMALL_LEVELS consecutive coarse levels: per iteration
+// the same per-record pipeline as k_reduce over the pair's valid-point list, a workgroup reduction, and the control step
+// of base_robust_dvo.py:166-232 (gn_control, one lane) — no launch per iteration, no partial sums through HBM, no
+// host-enqueued launches for pairs that have already stopped.  At 160x120 and below a level holds fewer records than one
+// launch of k_reduce needs workgroups to fill the chip, and its iterations are a chain of ~12 us launches plus a control
+// launch each: here an iteration costs the records' arithmetic plus two barriers.
+// The Student-t IRLS (weighter/t_weighter.py:21-34) runs as the reference's loop (until |d lambda| < 1e-3, at most 50
+// passes), the residuals of a pose kept between its passes.
+#define DVO_SMALL_MAX_THREADS 1024
+#define DVO_SMALL_MAX_WAVES (DVO_SMALL_MAX_THREADS / 64)
+
+// Wave totals (float64) of the DVO_NACC per-lane float32 sums -> out[0..31] (LDS).  Transposed through a wave-private LDS
+// region eight terms at a time: lane l adds eight of the 64 values of term l & 7 in float64 (conflict-free reads), three
+// shuffles join the eight segments.  Wave-synchronous: no workgroup barrier.
+__device__ __forceinline__ void wave_reduce_terms(const float* acc, float* wbuf /* [8][65] */, double* out)
+{
+    const int lane = threadIdx.x & 63;
+    const int term = lane & 7, seg = lane >> 3;
+#pragma unroll
+    for (int c = 0; c < (DVO_NACC + 7) / 8; ++c) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();                    // loads of the previous chunk are done
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+            if (c * 8 + i < DVO_NACC) wbuf[i * 65 + lane] = acc[c * 8 + i];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        double sgm = 0.0;
+        const float* src = wbuf + term * 65 + seg * 8;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) sgm += (double)src[k];
+        sgm += __shfl_xor(sgm, 8, 64);
+        sgm += __shfl_xor(sgm, 16, 64);
+        sgm += __shfl_xor(sgm, 32, 64);
+        if (seg == 0 && c * 8 + term < DVO_NACC) out[c * 8 + term] = sgm;
+    }
+    if (lane >= DVO_NACC && lane < DVO_STRIDE) out[lane] = 0.0;
+}
+
+template <int VARIANT, int WMODE, bool SKEW>
+__global__ __launch_bounds__(DVO_SMALL_MAX_THREADS) void k_gn_small(const DvoSmallParams p)
+{
+    static_assert(VARIANT == 0 || VARIANT == 1, "V3 keeps the per-iteration launches");
+    __shared__ DvoPairState st;
+    __shared__ float T_sh[12];
+    __shared__ int active_sh;
+    __shared__ double wpar_sh;
+    __shared__ double rec_sh[DVO_STRIDE];
+    __shared__ double wsum[DVO_SMALL_MAX_WAVES][DVO_STRIDE];
+    __shared__ double scal[2][DVO_SMALL_MAX_WAVES];
+    __shared__ float wbuf[DVO_SMALL_MAX_WAVES][8 * 65];
+    const int pair = blockIdx.x, tid = threadIdx.x;
+    const int lane_ = tid & 63, wave_ = tid >> 6, nwaves = (int)blockDim.x >> 6;
+    if (tid == 0) { st = p.state[pair]; active_sh = 1; wpar_sh = p.wparam[pair]; }
+    if (tid < 12) T_sh[tid] = p.T[(size_t)pair * 12 + tid];
+    const int prev_id = p.prev_slot[pair];
+    const uint8_t* prev = p.slots + (size_t)prev_id * p.slot_stride;
+    const uint8_t* curs = p.slots + (size_t)p.cur_slot[pair] * p.slot_stride;
+    const int gstride = (int)blockDim.x * DVO_PX_PER_THREAD;                      // records per group of the workgroup
+    const int rec0 = wave_ * (64 * DVO_PX_PER_THREAD);
+
+    for (int li = 0; li < p.n_levels; ++li) {
+        const DvoLevelGeom& g = p.g[li];
+        const DvoLevelCam& cam = p.cam[li];
+        const uint32_t* packed_prev = reinterpret_cast<const uint32_t*>(prev + g.off_packed);
+        const uint32_t* packed_cur = reinterpret_cast<const uint32_t*>(curs + g.off_packed);
+        const DvoPointRec* list = reinterpret_cast<const DvoPointRec*>(prev + g.off_list);
+        const int count = p.list_count[prev_id * DVO_LIST_LEVELS + p.level_id[li]];
+        float* rc_mine = (p.rcache != nullptr) ? p.rcache + (size_t)pair * p.rcache_stride : nullptr;
+        if (tid == 0) {
+            // start of a pyramid level (k_level_begin): err_prev = FLT_MAX, err_increased_count = 0 (base_robust_dvo.py:158-159),
+            // old = last_estimated_transform.copy() (:154)
+            st.err_prev = DVO_FLT_MAX;
+            st.increased = 0;
+            st.active = 1;
+            active_sh = 1;
+            for (int k = 0; k < 4; ++k) st.oq[k] = st.lq[k];
+            for (int k = 0; k < 3; ++k) st.ot[k] = st.lt[k];
+            if (WMODE == 1) wpar_sh = p.lambda0;                                           // t_weighter.py:23
+            if (WMODE == 2) wpar_sh = (st.lambda > 0.0) ? st.lambda : DVO_FLT_MAX;        // no scale yet: w = 1
+        }
+        __syncthreads();
+        for (int it = 0; it < p.max_iterations; ++it) {
+            if (active_sh == 0) break;                    // workgroup-uniform: written before the barrier that ended the last iteration
+            // the pose is workgroup-uniform: keep it in SGPRs like k_reduce does (LDS loads land in VGPRs)
+            float T[12];
+#pragma unroll
+            for (int i = 0; i < 12; ++i) T[i] = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(T_sh[i])));
+            float wpar = 0.0f;
+            if constexpr (WMODE == 2) wpar = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint((float)wpar_sh)));
+            if constexpr (WMODE == 1) {
+                // TDistributionWeighter.weight (weighter/t_weighter.py:21-34): lambda <- 1 / scale(lambda) until |d lambda| < 1e-3
+                double last = p.lambda0, cur = p.lambda0;
+                for (int pass = 0; pass < 50; ++pass) {
+                    const float lamf = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint((float)last)));
+                    float sacc = 0.0f;
+                    for (int seg = rec0; seg < count; seg += gstride) {          // wave-uniform bounds
+                        float r[DVO_PX_PER_THREAD];
+                        if (pass == 0 || rc_mine == nullptr) {
+                            uint2 rc[DVO_PX_PER_THREAD];
+                            PixelGeo geo[DVO_PX_PER_THREAD];
+                            PixelTaps taps[DVO_PX_PER_THREAD];
+#pragma unroll
+                            for (int j = 0; j < DVO_PX_PER_THREAD; ++j) rc[j] = *reinterpret_cast<const uint2*>(list + seg + j * 64 + lane_);
+#pragma unroll
+                            for (int j = 0; j < DVO_PX_PER_THREAD; ++j) {
+                                const bool live = (seg + j * 64 + lane_) < count;
+                                const unsigned pix = rc[j].y;
+                                dvo_geo<SKEW>(g, cam, T, (float)(pix & 0xfffu), (float)((pix >> 12) & 0xfffu), __uint_as_float(rc[j].x), live, geo[j]);
+                                dvo_load_taps(g, packed_cur, geo[j], taps[j]);
+                                taps[j].own = 0u;
+                            }
+#pragma unroll
+                            for (int j = 0; j < DVO_PX_PER_THREAD; ++j) {
+                                r[j] = __builtin_nanf("");
+                                if (geo[j].ok) {
+                                    PixelOut o;
+                                    dvo_finish<VARIANT, false>(cam, geo[j], taps[j], rc[j].y >> 24, o);
+                                    r[j] = o.r;
+                                }
+                            }
+                            if (rc_mine != nullptr) {
+#pragma unroll
+                                for (int j = 0; j < DVO_PX_PER_THREAD; ++j)
+                                    if (seg + j * 64 + lane_ < count) rc_mine[seg + j * 64 + lane_] = r[j];
+                            }
+                        } else {
+#pragma unroll
+                            for (int j = 0; j < DVO_PX_PER_THREAD; ++j) {
+                                const int idx = seg + j * 64 + lane_;
+                                r[j] = (idx < count) ? rc_mine[idx] : __builtin_nanf("");
+                            }
+                        }
+#pragma unroll
+                        for (int j = 0; j < DVO_PX_PER_THREAD; ++j) {
+                            if (r[j] == r[j]) {
+                                const float r2 = r[j] * r[j];
+                                sacc += r2 * (6.0f * fast_rcp(fmaf(r2, lamf, 5.0f)));       // t_weighter.py:43-45, dof = 5
+                            }
+                        }
+                    }
+                    const double sw = wave_sum((double)sacc);
+                    if (lane_ == 0) scal[pass & 1][wave_] = sw;
+                    __syncthreads();
+                    double S = 0.0;
+                    for (int w = 0; w < nwaves; ++w) S += scal[pass & 1][w];      // every thread, same order: same S
+                    cur = 1.0 / S;
+                    if (fabs(cur - last) < 1e-3) break;                             // uniform
+                    last = cur;
+                }
+                wpar = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint((float)cur)));
+            }
+
+            float acc[DVO_NACC];
+#pragma unroll
+            for (int i = 0; i < DVO_NACC; ++i) acc[i] = 0.0f;
+            for (int seg = rec0; seg < count; seg += gstride) {                     // wave-uniform bounds
+                uint2 rc[DVO_PX_PER_THREAD];
+                PixelGeo geo[DVO_PX_PER_THREAD];
+                PixelTaps taps[DVO_PX_PER_THREAD];
+#pragma unroll
+                for (int j = 0; j < DVO_PX_PER_THREAD; ++j) rc[j] = *reinterpret_cast<const uint2*>(list + seg + j * 64 + lane_);
+#pragma unroll
+                for (int j = 0; j < DVO_PX_PER_THREAD; ++j) {
+                    const bool live = (seg + j * 64 + lane_) < count;
+                    const unsigned pix = rc[j].y;
+                    const unsigned xi = pix & 0xfffu, yi = (pix >> 12) & 0xfffu;
+                    dvo_geo<SKEW>(g, cam, T, (float)xi, (float)yi, __uint_as_float(rc[j].x), live, geo[j]);
+                    dvo_load_taps(g, packed_cur, geo[j], taps[j]);
+                    taps[j].own = 0u;
+                    if (VARIANT == 1) taps[j].own = geo[j].ok ? packed_prev[yi * (unsigned)g.pitch + xi] : 0u;
+                }
+#pragma unroll
+                for (int j = 0; j < DVO_PX_PER_THREAD; ++j) {
+                    if (geo[j].ok) {
+                        PixelOut o;
+                        dvo_finish<VARIANT, true>(cam, geo[j], taps[j], rc[j].y >> 24, o);
+                        const float r = o.r;
+                        const float r2 = r * r;
+                        float wt = 1.0f;
+                        if (WMODE == 1) wt = 6.0f * fast_rcp(fmaf(r2, wpar, 5.0f));              // t_weighter.py:34
+                        if (WMODE == 2) { const float ar = fabsf(r); wt = (ar <= wpar) ? 1.0f : wpar * fast_rcp(ar); }
+                        float wj[6];
+#pragma unroll
+                        for (int k = 0; k < 6; ++k) wj[k] = (WMODE == 0) ? o.J[k] : wt * o.J[k];
+                        int q = 0;
+#pragma unroll
+                        for (int a = 0; a < 6; ++a)
+#pragma unroll
+                            for (int b = a; b < 6; ++b) { acc[q] = fmaf(wj[a], o.J[b], acc[q]); ++q; }
+#pragma unroll
+                        for (int k = 0; k < 6; ++k) acc[21 + k] = fmaf(wj[k], r, acc[21 + k]);
+                        acc[27] = fmaf((WMODE == 0) ? r : wt * r, r, acc[27]);
+                        acc[28] += 1.0f;
+                        if (WMODE != 0) acc[29] += r2;
+                    }
+                }
+            }
+            if constexpr (WMODE == 0) acc[DVO_NACC - 1] = acc[DVO_NACC - 3];
+            wave_reduce_terms(acc, wbuf[wave_], wsum[wave_]);
+            __syncthreads();
+            if (tid < DVO_STRIDE) {
+                double t = 0.0;
+                for (int w = 0; w < nwaves; ++w) t += wsum[w][tid];                  // fixed order
+                rec_sh[tid] = t;
+            }
+            __syncthreads();
+            if (tid == 0) gn_control(p, 0, pair, st, T_sh, &active_sh, &wpar_sh, rec_sh);
+            __syncthreads();
+        }
+        __syncthreads();
+    }
+    if (tid == 0) { p.state[pair] = st; p.active[pair] = active_sh; p.wparam[pair] = wpar_sh; }
+    if (tid < 12) p.T[(size_t)pair * 12 + tid] = T_sh[tid];
+}
+
+hipError_t dvo_launch_gn_small(const DvoSmallParams& p, int variant, int threads, hipStream_t s)
+{
+    const dim3 grid((unsigned)p.n_pairs), block((unsigned)threads);
+    const bool skew = !p.cam[0].skew0;
+#define DVO_SMALL_LAUNCH(V, W, S) hipLaunchKernelGGL((k_gn_small<V, W, S>), grid, block, 0, s, p)
+#define DVO_SMALL_W(V, S)                                                     \
+    do {                                                                      \
+        if (p.weight_mode == 0) DVO_SMALL_LAUNCH(V, 0, S);                    \
+        else if (p.weight_mode == 1) DVO_SMALL_LAUNCH(V, 1, S);               \
+        else DVO_SMALL_LAUNCH(V, 2, S);                                       \
+    } while (0)
+    if (variant == 0) { if (skew) DVO_SMALL_W(0, true); else DVO_SMALL_W(0, false); }
+    else if (variant == 1) { if (skew) DVO_SMALL_W(1, true); else DVO_SMALL_W(1, false); }
+    else return hipErrorInvalidValue;
+#undef DVO_SMALL_W
+#undef DVO_SMALL_LAUNCH
     return hipGetLastError();
 }
 
