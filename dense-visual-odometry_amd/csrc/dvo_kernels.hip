@@ -736,15 +736,16 @@ __device__ __forceinline__ void dvo_finish(const DvoLevelCam& cam, const PixelGe
     // both within 2e-7 relative of the reference's float32 quotients, far inside the 1e-5 bound on the increments.
     const float iz = __builtin_amdgcn_rcpf(q.z);
     const float a = q.x, b = q.y;
-    const float fxg = cam.fx * gxw, fyg = cam.fy * gyw;
-    // J = gx * Jw[0,:] + gy * Jw[1,:]   (_fill_jacobian, cpu_robust...:79-90)
-    const float ab = a * b;
-    o.J[0] = fxg * iz;
-    o.J[1] = fyg * iz;
-    o.J[2] = -fmaf(fxg, a, fyg * b) * iz;
-    o.J[3] = -fmaf(fxg, ab, fyg * fmaf(b, b, 1.0f));
-    o.J[4] = fmaf(fxg, fmaf(a, a, 1.0f), fyg * ab);
-    o.J[5] = fmaf(fyg, a, -(fxg * b));
+    const float p = cam.fx * gxw, qq = cam.fy * gyw;
+    // J = gx * Jw[0,:] + gy * Jw[1,:]   (_fill_jacobian, cpu_robust...:79-90), with the common factor m = p a + q b taken out:
+    //   -(p ab + q (1 + b^2)) = -(b m + q),   p (1 + a^2) + q ab = a m + p        (11 instructions instead of 16)
+    const float m = fmaf(p, a, qq * b);
+    o.J[0] = p * iz;
+    o.J[1] = qq * iz;
+    o.J[2] = -(m * iz);
+    o.J[3] = -fmaf(b, m, qq);
+    o.J[4] = fmaf(a, m, p);
+    o.J[5] = fmaf(qq, a, -(p * b));
 }
 
 // Test hook: out[i] = the kernels' quotient a[i]/b[i]; ref[i] = the compiler's IEEE division.
@@ -779,7 +780,10 @@ __device__ __forceinline__ double wave_sum(double v)
 // ([term][thread], padded so stores and loads are bank-conflict free), then 8 lanes per term each add 32 of the 256
 // values in float64 (fixed order => reproducible), and a 3-step shuffle joins the 8 segments.  Two rounds of 15
 // terms keep the LDS footprint at 15.5 KB per workgroup.
-__device__ __forceinline__ void block_reduce_terms(const float* acc, double* out)
+// DVO_CLOCK_PROBE (diagnostic build, tools/clock_probe.py; never in the product library): the two reserved slots of the
+// record carry, summed over the workgroups of a pair, the shader-clock ticks (s_memtime) and the constant 100 MHz ticks
+// (s_memrealtime) each workgroup's first wave spent in the kernel body: their ratio is the clock the chip really holds.
+__device__ __forceinline__ void block_reduce_terms(const float* acc, double* out, unsigned long long t0 = 0, unsigned long long r0 = 0)
 {
     constexpr int ROW = 8 * 33;                          // 8 segments of 32 values + 1 pad each
     constexpr int HALF = 15;
@@ -804,7 +808,12 @@ __device__ __forceinline__ void block_reduce_terms(const float* acc, double* out
         sgm += __shfl_xor(sgm, 4, 64);
         if (t < HALF * 8 && segi == 0) out[round * HALF + term] = sgm;
     }
+#ifdef DVO_CLOCK_PROBE
+    if (t == 30) out[t] = (double)(__builtin_amdgcn_s_memtime() - t0);
+    if (t == 31) out[t] = (double)(__builtin_amdgcn_s_memrealtime() - r0);
+#else
     if (t >= 30 && t < DVO_STRIDE) out[t] = 0.0;
+#endif
 }
 
 #ifndef DVO_REDUCE_WAVES_PER_SIMD
@@ -858,6 +867,11 @@ __global__ __launch_bounds__(DVO_BLOCK, (VARIANT == 2) ? 2 : DVO_REDUCE_WAVES_PE
     const int pair = lb / p.blocks_per_pair;
     const int blk = lb - pair * p.blocks_per_pair;
     if (p.active != nullptr && p.active[pair] == 0) return;        // block-uniform
+#ifdef DVO_CLOCK_PROBE
+    const unsigned long long probe_t0 = __builtin_amdgcn_s_memtime(), probe_r0 = __builtin_amdgcn_s_memrealtime();
+#else
+    const unsigned long long probe_t0 = 0, probe_r0 = 0;
+#endif
 
     const uint8_t* prev = p.slots + (size_t)p.prev_slot[pair] * p.slot_stride;
     const uint8_t* curs = p.slots + (size_t)p.cur_slot[pair] * p.slot_stride;
@@ -1009,7 +1023,7 @@ __global__ __launch_bounds__(DVO_BLOCK, (VARIANT == 2) ? 2 : DVO_REDUCE_WAVES_PE
         }
     } else {
         double* out = p.partials + ((size_t)pair * p.blocks_per_pair + blk) * DVO_STRIDE;
-        block_reduce_terms(acc, out);
+        block_reduce_terms(acc, out, probe_t0, probe_r0);
     }
 }
 

@@ -8,7 +8,7 @@ for round in 1 2; do
 import sys, json
 d = json.loads(sys.stdin.read().strip().splitlines()[-1])
 r = d['roofline']
-print('$lib round $round: %.0f pairs/s  L0 %.1f us  levels %s' % (d['value'], r['avg_launch_us'], ' '.join('%.1f' % v['avg_us'] for v in r['per_level'].values())))
+print('$lib round $round: %.0f pairs/s  L0 %.1f us  levels %s' % (d['value'], r['avg_launch_us'], ' '.join(('%.1f' % v['avg_us']) if v['avg_us'] else '-' for v in r['per_level'].values())))
 " | tee -a gpurun_out/ab_bench.log
   done
 done
