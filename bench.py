@@ -54,7 +54,7 @@ def parse_args():
     ap.add_argument("--height", type=int, default=480)
     ap.add_argument("--levels", type=int, default=4)
     ap.add_argument("--iterations", type=int, default=10)
-    ap.add_argument("--weighting", default="none", choices=["none", "student_t_reference", "huber"])
+    ap.add_argument("--weighting", default="none", choices=["none", "student_t_reference", "student_t", "huber"])
     ap.add_argument("--variant", default="v1", choices=["v1", "v2", "v3"],
                     help="v1: reference CPU default (the metric); v2: approximate_image2_gradient; v3: numba.cuda kernel semantics")
     ap.add_argument("--streams", type=int, default=4, help="independent HIP streams (sub-batches) per GPU")

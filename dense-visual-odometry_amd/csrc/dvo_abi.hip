@@ -81,6 +81,7 @@ struct dvo_ctx {
     uint8_t* d_stage_img = nullptr;      // staging for host->device image uploads (bgr needs 3 B/px + depth)
     uint8_t* d_batch_stage = nullptr;    // staging of dvo_upload_frames (whole batches), grown on demand
     size_t batch_stage_bytes = 0;
+    int* d_irls_done = nullptr;          // Student-t device solve with control launches: per pair, IRLS converged for this iteration
     double* d_scale1 = nullptr;          // Student-t device solve: per-workgroup sums of the two scale passes
     double* d_scale2 = nullptr;
     float* d_rcache = nullptr;           // Student-t device solve: residuals kept between the scale passes [max_pairs][max_w*max_h]
@@ -305,6 +306,7 @@ int fill_reduce_params(dvo_ctx* ctx, int level, int n_pairs, int w, int h, DvoRe
     p->list_count = ctx->d_list_count;
     p->level = level;
     p->rcache = nullptr;
+    p->irls_done = nullptr;
     p->scale_out = nullptr;
     p->scale1 = nullptr;
     p->scale2 = nullptr;
@@ -434,6 +436,7 @@ int dvo_create(int device, int max_w, int max_h, int max_levels, int n_slots, in
     CREATE_TRY(hipMalloc((void**)&ctx->d_Tinit, np * 12 * sizeof(float)));
     CREATE_TRY(hipMalloc((void**)&ctx->d_wparam, np * sizeof(double)));
     CREATE_TRY(hipMalloc((void**)&ctx->d_active, np * sizeof(int)));
+    CREATE_TRY(hipMalloc((void**)&ctx->d_irls_done, np * sizeof(int)));
     CREATE_TRY(hipMalloc((void**)&ctx->d_frame_slots, (size_t)n_slots * sizeof(int)));
     CREATE_TRY(hipHostMalloc((void**)&ctx->h_frame_slots, 4 * (size_t)n_slots * sizeof(int)));
     for (int i = 0; i < 4; ++i) CREATE_TRY(hipEventCreateWithFlags(&ctx->ev_fs[i], hipEventDisableTiming));
@@ -509,7 +512,7 @@ void dvo_destroy(dvo_ctx* ctx)
     if (ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);
     void* dev[] = {ctx->d_slots, ctx->d_prev, ctx->d_cur, ctx->d_T, ctx->d_Tinit, ctx->d_wparam, ctx->d_active, ctx->d_partials,
                    ctx->d_out, ctx->d_state, ctx->d_xi, ctx->d_iters, ctx->d_err, ctx->d_stage_img, ctx->d_dense, ctx->d_trace, ctx->d_frame_slots, ctx->d_prior, ctx->d_batch_stage,
-                   ctx->d_list_count, ctx->d_seg_counts, ctx->d_rcache, ctx->d_scale1, ctx->d_scale2};
+                   ctx->d_list_count, ctx->d_seg_counts, ctx->d_rcache, ctx->d_scale1, ctx->d_scale2, ctx->d_irls_done};
     for (void* p : dev) if (p) (void)hipFree(p);
     void* host[] = {ctx->hs.prev, ctx->hs.cur, ctx->hs.T, ctx->hs.wparam, ctx->hs.out, ctx->hs.xi, ctx->hs.iters, ctx->hs.err, ctx->h_frame_slots, ctx->h_prior};
     for (void* p : host) if (p) (void)hipHostFree(p);
@@ -845,7 +848,7 @@ int dvo_normal_equations(dvo_ctx* ctx, int level, int n_pairs, const int* prev_s
     if (!ctx) return DVO_ERR_INVALID_ARG;
     if (!T || !out) return fail(ctx, DVO_ERR_INVALID_ARG, "dvo_normal_equations: null T/out");
     if (level < 0) return fail(ctx, DVO_ERR_INVALID_ARG, "level %d < 0", level);
-    if (weight_mode < 0 || weight_mode > 2) return fail(ctx, DVO_ERR_INVALID_ARG, "weight_mode %d unknown", weight_mode);
+    if (weight_mode < 0 || weight_mode > 3) return fail(ctx, DVO_ERR_INVALID_ARG, "weight_mode %d unknown", weight_mode);
     if (weight_mode != 0 && !weight_param) return fail(ctx, DVO_ERR_INVALID_ARG, "weight_param required for weight_mode %d", weight_mode);
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     int rc = check_variant(ctx, variant);
@@ -888,6 +891,34 @@ int dvo_weighted_r2_sum(dvo_ctx* ctx, int level, int n_pairs, const int* prev_sl
     HIP_TRY(ctx, hipMemcpyAsync(ctx->hs.out, ctx->d_out, (size_t)n_pairs * DVO_STRIDE * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     for (int i = 0; i < n_pairs; ++i) out[i] = ctx->hs.out[(size_t)i * DVO_STRIDE];
+    return DVO_OK;
+}
+
+int dvo_weighted_r2_stats(dvo_ctx* ctx, int level, int n_pairs, const int* prev_slot, const int* cur_slot,
+                          const float* T, int variant, const double* lambda, double* stats)
+{
+    if (!ctx) return DVO_ERR_INVALID_ARG;
+    if (!T || !stats || !lambda) return fail(ctx, DVO_ERR_INVALID_ARG, "dvo_weighted_r2_stats: null argument");
+    if (level < 0) return fail(ctx, DVO_ERR_INVALID_ARG, "level %d < 0", level);
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    int rc = check_variant(ctx, variant);
+    if (rc) return rc;
+    int w, h;
+    rc = check_pairs(ctx, n_pairs, prev_slot, cur_slot, level, &w, &h);
+    if (rc) return rc;
+    rc = stage_pairs(ctx, n_pairs, prev_slot, cur_slot, T, lambda);
+    if (rc) return rc;
+    DvoReduceParams p;
+    rc = fill_reduce_params(ctx, level, n_pairs, w, h, &p);
+    if (rc) return rc;
+    HIP_TRY(ctx, launch_reduce_profiled(ctx, p, level, variant, 1, 1));
+    HIP_TRY(ctx, dvo_launch_sum_partials(ctx->d_partials, p.blocks_per_pair, n_pairs, ctx->d_out, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->hs.out, ctx->d_out, (size_t)n_pairs * DVO_STRIDE * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    for (int i = 0; i < n_pairs; ++i) {
+        stats[2 * i] = ctx->hs.out[(size_t)i * DVO_STRIDE];
+        stats[2 * i + 1] = ctx->hs.out[(size_t)i * DVO_STRIDE + 1];
+    }
     return DVO_OK;
 }
 
@@ -936,6 +967,7 @@ static int record_solve(dvo_ctx* ctx, const SolveKey& k, const float* d_init)
     const double tolerance = k.tolerance, weight_param = k.weight_param;
     int rc;
     const double lambda0 = 1.0 / 25.0;                      // TDistributionWeighter: initial_sigma = 5 (t_weighter.py:11-15)
+    HIP_TRY(ctx, hipMemsetAsync(ctx->d_irls_done, 0, (size_t)n_pairs * sizeof(int), ctx->stream));
     HIP_TRY(ctx, dvo_launch_init_state(ctx->d_state, ctx->d_T, d_init, n_pairs, lambda0,
                                        (k.inv_sigma > 0.0 && k.has_last) ? ctx->d_prior : nullptr, ctx->stream));
     // The coarsest levels (at most knobs.small_max_pix pixels each) run in ONE persistent launch, a workgroup per pair
@@ -968,7 +1000,8 @@ static int record_solve(dvo_ctx* ctx, const SolveKey& k, const float* d_init)
             sp.T = ctx->d_T;
             sp.active = ctx->d_active;
             sp.wparam = ctx->d_wparam;
-            sp.rcache = (weight_mode == DVO_WEIGHT_STUDENT_T) ? ctx->d_rcache : nullptr;
+            sp.rcache = (weight_mode == DVO_WEIGHT_STUDENT_T || weight_mode == DVO_WEIGHT_STUDENT_T_MEAN) ? ctx->d_rcache : nullptr;
+            sp.student_t_mean = (weight_mode == DVO_WEIGHT_STUDENT_T_MEAN) ? 1 : 0;
             sp.rcache_stride = (size_t)ctx->max_w * ctx->max_h;
             sp.tolerance = tolerance;
             sp.max_increased = max_increased_steps_allowed;
@@ -1018,15 +1051,17 @@ static int record_solve(dvo_ctx* ctx, const SolveKey& k, const float* d_init)
         sp.trace = ctx->d_trace;
         sp.trace_stride = DVO_STRIDE + 18;
         sp.trace_cap = ctx->trace_cap;
+        sp.irls_done = nullptr;
+        sp.phase = 0;
         HIP_TRY(ctx, dvo_launch_level_begin(ctx->d_state, ctx->d_active, ctx->d_wparam, n_pairs, weight_mode, lambda0, ctx->stream));
         for (int it = 0; it < max_iterations; ++it) {
-            if (weight_mode == DVO_WEIGHT_STUDENT_T) {
-                // the two IRLS scale passes the reference's loop takes (weighter/t_weighter.py:24-32)
-                // (the first pass keeps the residuals of this pose; the second sums them again under the new lambda)
+            if (weight_mode == DVO_WEIGHT_STUDENT_T || weight_mode == DVO_WEIGHT_STUDENT_T_MEAN) {
+                // IRLS scale passes (weighter/t_weighter.py:24-32): the first keeps the residuals of this pose, the later ones sum
+                // them again under the new lambda
                 p.rcache = ctx->d_rcache;
-                if (ctx->d_rcache != nullptr && ctx->d_scale1 != nullptr && !ctx->knobs.st_solve_phases) {
-                    // no control launch between the three passes: each kernel derives its lambda from the per-workgroup sums
-                    // of the passes before it (same summation order as k_solve => same lambda, bit for bit)
+                if (weight_mode == DVO_WEIGHT_STUDENT_T && ctx->d_rcache != nullptr && ctx->d_scale1 != nullptr && !ctx->knobs.st_solve_phases) {
+                    // the reference's form, two passes, no control launch between the three kernels: each derives its lambda from the
+                    // per-workgroup sums of the passes before it (same summation order as k_solve => same lambda, bit for bit)
                     p.scale_out = ctx->d_scale1;
                     HIP_TRY(ctx, launch_reduce_profiled(ctx, p, level, variant, 1, 1));
                     p.scale_out = ctx->d_scale2;
@@ -1035,12 +1070,18 @@ static int record_solve(dvo_ctx* ctx, const SolveKey& k, const float* d_init)
                     p.scale_out = nullptr;
                     p.scale2 = ctx->d_scale2;
                 } else {
-                    for (int pass = 1; pass <= 2; ++pass) {
+                    // a control launch after every pass (k_solve, phase > 0) updates lambda and the per-pair converged flag; the
+                    // workgroups of a converged pair leave the remaining passes at once
+                    const int npass = (weight_mode == DVO_WEIGHT_STUDENT_T_MEAN) ? 4 : 2;
+                    p.irls_done = ctx->d_irls_done;
+                    sp.irls_done = ctx->d_irls_done;
+                    for (int pass = 1; pass <= npass; ++pass) {
                         if (pass == 1 || ctx->d_rcache == nullptr) HIP_TRY(ctx, launch_reduce_profiled(ctx, p, level, variant, 1, 1));
                         else HIP_TRY(ctx, dvo_launch_scale_cached(p, ctx->stream));
                         sp.phase = pass;
                         HIP_TRY(ctx, dvo_launch_solve(sp, ctx->stream));
                     }
+                    p.irls_done = nullptr;
                 }
                 p.rcache = nullptr;
             }
@@ -1062,7 +1103,7 @@ int dvo_solve_batch_enqueue(dvo_ctx* ctx, int n_pairs, const int* prev_slot, con
 {
     if (!ctx) return DVO_ERR_INVALID_ARG;
     if (levels < 1 || max_iterations < 0) return fail(ctx, DVO_ERR_INVALID_ARG, "levels %d / max_iterations %d invalid", levels, max_iterations);
-    if (weight_mode < 0 || weight_mode > 2) return fail(ctx, DVO_ERR_INVALID_ARG, "weight_mode %d unknown", weight_mode);
+    if (weight_mode < 0 || weight_mode > 3) return fail(ctx, DVO_ERR_INVALID_ARG, "weight_mode %d unknown", weight_mode);
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     int rc = check_variant(ctx, variant);
     if (rc) return rc;
@@ -1071,7 +1112,7 @@ int dvo_solve_batch_enqueue(dvo_ctx* ctx, int n_pairs, const int* prev_slot, con
     if (rc) return rc;
     rc = stage_pairs(ctx, n_pairs, prev_slot, cur_slot, nullptr, nullptr);
     if (rc) return rc;
-    if (weight_mode == DVO_WEIGHT_STUDENT_T && ctx->d_rcache == nullptr && !ctx->knobs.no_rcache) {
+    if ((weight_mode == DVO_WEIGHT_STUDENT_T || weight_mode == DVO_WEIGHT_STUDENT_T_MEAN) && ctx->d_rcache == nullptr && !ctx->knobs.no_rcache) {
         // residual cache of the scale passes (allocated on first use, outside any graph capture); without it the second
         // pass recomputes the residuals
         if (hipMalloc((void**)&ctx->d_rcache, (size_t)ctx->max_pairs * ctx->max_w * ctx->max_h * sizeof(float)) != hipSuccess) {

@@ -67,6 +67,8 @@ struct DvoReduceParams {
     const double* scale2;       //     between the three passes of an iteration); all null: lambda comes from wparam
     float* rcache;              // Student-t scale passes: [n_pairs][g.npix] residual of every record of the current pose
                                 // (NaN: out of bounds), written by the first pass and read by the second; or null
+    const int* irls_done;       // Student-t scale passes with control launches: [n_pairs] 1 once a pair's IRLS has converged for this
+                                // iteration (its workgroups exit at once); or null
 };
 
 struct DvoDenseParams {
@@ -111,7 +113,8 @@ struct DvoSolveParams {
     int weight_mode;
     double weight_param;        // huber: k multiplier
     double inv_sigma;           // motion prior 1/sigma (base_robust_dvo.py:69-71), 0 = off
-    int phase;                  // 0: normal-equation iteration; 1/2: student-t scale passes
+    int phase;                  // 0: normal-equation iteration; 1..: student-t scale passes
+    int* irls_done;             // [n_pairs] see DvoReduceParams, or null
     double* trace;              // optional [n_pairs][max_trace][DVO_STRIDE+8] per-iteration records, or null
     int trace_stride, trace_cap;
 };
@@ -146,6 +149,7 @@ struct DvoSmallParams {
     double inv_sigma;
     double lambda0;              // Student-t: 1 / initial_sigma^2
     int student_t_mean;          // Student-t scale = mean (proper) instead of the reference's sum (quirk Q3)
+    int* irls_done;              // unused here (the IRLS loop runs inside the kernel); null
     double* trace;
     int trace_stride, trace_cap;
 };

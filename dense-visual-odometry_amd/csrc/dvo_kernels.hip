@@ -855,7 +855,7 @@ __device__ __forceinline__ double student_t_lambda(const DvoReduceParams& p, int
 template <int VARIANT, int WMODE, bool SCALE_PASS, int TAG, bool SKEW>
 __global__ __launch_bounds__(DVO_BLOCK, (VARIANT == 2) ? 2 : DVO_REDUCE_WAVES_PER_SIMD) void k_reduce(const DvoReduceParams p)
 {
-    constexpr int NACC = SCALE_PASS ? 1 : DVO_NACC;
+    constexpr int NACC = SCALE_PASS ? 2 : DVO_NACC;       // scale pass: sum of the weighted r^2, number of residuals
     // XCD-aware block order (speed only): workgroups are dealt round-robin to the 8 XCDs, so give XCD k the
     // k-th contiguous eighth of the logical grid; the workgroups of one frame pair (which share tap rows of the
     // packed plane) then run behind one L2.  Bijective for any grid size.
@@ -867,6 +867,9 @@ __global__ __launch_bounds__(DVO_BLOCK, (VARIANT == 2) ? 2 : DVO_REDUCE_WAVES_PE
     const int pair = lb / p.blocks_per_pair;
     const int blk = lb - pair * p.blocks_per_pair;
     if (p.active != nullptr && p.active[pair] == 0) return;        // block-uniform
+    if constexpr (SCALE_PASS) {
+        if (p.irls_done != nullptr && p.irls_done[pair] != 0) return;      // this pair's IRLS has converged: nothing to sum
+    }
 #ifdef DVO_CLOCK_PROBE
     const unsigned long long probe_t0 = __builtin_amdgcn_s_memtime(), probe_r0 = __builtin_amdgcn_s_memrealtime();
 #else
@@ -905,29 +908,32 @@ __global__ __launch_bounds__(DVO_BLOCK, (VARIANT == 2) ? 2 : DVO_REDUCE_WAVES_PE
     const int lane_ = threadIdx.x & 63, wave_ = threadIdx.x >> 6;
     const DvoPointRec* list = reinterpret_cast<const DvoPointRec*>(prev + p.g.off_list);
     const int count = p.list_count[p.prev_slot[pair] * DVO_LIST_LEVELS + p.level];
-    // Groups of 1024 records are dealt round-robin to the workgroups of the pair (group g -> workgroup g mod n): the list is
-    // shorter than the pixel count the grid was sized for, and this way every workgroup gets the same share of it whatever
-    // its length (a contiguous split leaves the last workgroups of every pair empty and the launch unbalanced).
-    const int gstride = p.blocks_per_pair * (DVO_BLOCK / 64) * (64 * DVO_PX_PER_THREAD);
-    const int rec0 = (blk * (DVO_BLOCK / 64) + wave_) * (64 * DVO_PX_PER_THREAD);   // wave-uniform
+    // The G = ceil(count / 1024) record groups of the pair are split into contiguous, count-balanced ranges: workgroup blk takes
+    // groups [blk G / n, (blk + 1) G / n).  Balanced whatever the list length (the grid is sized for the pixel count, the list is
+    // ~30 % shorter: a split by pixel index leaves the last workgroups empty), and contiguous, so that neighbouring workgroups
+    // do not both fetch the tap rows a round-robin deal of single groups makes them share (HBM traffic 886 -> ~760 MB per launch).
+    const int ngroups = (count + DVO_PX_PER_BLOCK - 1) / DVO_PX_PER_BLOCK;
+    const int g_lo = (blk * ngroups) / p.blocks_per_pair, g_hi = ((blk + 1) * ngroups) / p.blocks_per_pair;
+    const int wave_off = wave_ * (64 * DVO_PX_PER_THREAD);                            // wave-uniform
+    const int rec0 = g_lo * DVO_PX_PER_BLOCK + wave_off;
     // the records of the next group are requested one group ahead, so their latency is covered by the arithmetic of
     // the current group and only the dependent tap gathers are waited for
     uint2 rn[DVO_PX_PER_THREAD];
 #pragma unroll
     for (int j = 0; j < DVO_PX_PER_THREAD; ++j) rn[j] = make_uint2(0u, 0u);
-    if (rec0 < count) {
+    if (g_lo < g_hi && rec0 < count) {
 #pragma unroll
         for (int j = 0; j < DVO_PX_PER_THREAD; ++j) rn[j] = *reinterpret_cast<const uint2*>(list + rec0 + j * 64 + lane_);
     }
-    for (int grp = 0; grp < p.groups_per_block; ++grp) {
-        const int seg = rec0 + grp * gstride;
+    for (int grp = g_lo; grp < g_hi; ++grp) {
+        const int seg = grp * DVO_PX_PER_BLOCK + wave_off;
         if (seg >= count) break;                                          // wave-uniform
         uint2 rc[DVO_PX_PER_THREAD];
 #pragma unroll
         for (int j = 0; j < DVO_PX_PER_THREAD; ++j) rc[j] = rn[j];
         {
-            const int segn = seg + gstride;
-            if (grp + 1 < p.groups_per_block && segn < count) {           // (reads past `count` stay inside DVO_LIST_SLACK)
+            const int segn = seg + DVO_PX_PER_BLOCK;
+            if (grp + 1 < g_hi && segn < count) {                         // (reads past `count` stay inside DVO_LIST_SLACK)
 #pragma unroll
                 for (int j = 0; j < DVO_PX_PER_THREAD; ++j) rn[j] = *reinterpret_cast<const uint2*>(list + segn + j * 64 + lane_);
             }
@@ -971,6 +977,7 @@ __global__ __launch_bounds__(DVO_BLOCK, (VARIANT == 2) ? 2 : DVO_REDUCE_WAVES_PE
                 if constexpr (SCALE_PASS) {
                     // r^2 * (dof+1)/(dof + r^2*lambda), dof = 5 (weighter/t_weighter.py:43-45)
                     acc[0] += r2 * (6.0f * fast_rcp(fmaf(r2, wpar, 5.0f)));
+                    acc[1] += 1.0f;
                     rkeep[j] = r;
                 } else {
                     float wt = 1.0f;
@@ -1010,15 +1017,15 @@ __global__ __launch_bounds__(DVO_BLOCK, (VARIANT == 2) ? 2 : DVO_REDUCE_WAVES_PE
     // 32 of the 256 values in float64 (fixed order => reproducible), and a 3-step shuffle joins the 8 segments.
     // Two rounds of 15 terms keep the LDS footprint at 15.5 KB per workgroup.
     if constexpr (SCALE_PASS) {
-        __shared__ double lds1[DVO_BLOCK / 64];
-        const double sw = wave_sum((double)acc[0]);
-        if ((threadIdx.x & 63) == 0) lds1[threadIdx.x >> 6] = sw;
+        __shared__ double lds1[2][DVO_BLOCK / 64];
+        const double sw = wave_sum((double)acc[0]), cw = wave_sum((double)acc[1]);
+        if ((threadIdx.x & 63) == 0) { lds1[0][threadIdx.x >> 6] = sw; lds1[1][threadIdx.x >> 6] = cw; }
         __syncthreads();
         if (p.scale_out != nullptr) {
-            if (threadIdx.x == 0) p.scale_out[(size_t)pair * p.blocks_per_pair + blk] = (lds1[0] + lds1[1]) + (lds1[2] + lds1[3]);
+            if (threadIdx.x == 0) p.scale_out[(size_t)pair * p.blocks_per_pair + blk] = (lds1[0][0] + lds1[0][1]) + (lds1[0][2] + lds1[0][3]);
         } else if (threadIdx.x < DVO_STRIDE) {
             double tot = 0.0;
-            if (threadIdx.x == 0) tot = (lds1[0] + lds1[1]) + (lds1[2] + lds1[3]);
+            if (threadIdx.x < 2) tot = (lds1[threadIdx.x][0] + lds1[threadIdx.x][1]) + (lds1[threadIdx.x][2] + lds1[threadIdx.x][3]);
             p.partials[((size_t)pair * p.blocks_per_pair + blk) * DVO_STRIDE + threadIdx.x] = tot;
         }
     } else {
@@ -1036,15 +1043,17 @@ __global__ __launch_bounds__(DVO_BLOCK) void k_scale_cached(const DvoReduceParam
     const int pair = lb / p.blocks_per_pair;
     const int blk = lb - pair * p.blocks_per_pair;
     if (p.active != nullptr && p.active[pair] == 0) return;
+    if (p.irls_done != nullptr && p.irls_done[pair] != 0) return;
     const int lane_ = threadIdx.x & 63, wave_ = threadIdx.x >> 6;
     const int count = p.list_count[p.prev_slot[pair] * DVO_LIST_LEVELS + p.level];
-    const int gstride = p.blocks_per_pair * (DVO_BLOCK / 64) * (64 * DVO_PX_PER_THREAD);
-    const int rec0 = (blk * (DVO_BLOCK / 64) + wave_) * (64 * DVO_PX_PER_THREAD);
+    const int ngroups = (count + DVO_PX_PER_BLOCK - 1) / DVO_PX_PER_BLOCK;           // the same split as k_reduce
+    const int g_lo = (blk * ngroups) / p.blocks_per_pair, g_hi = ((blk + 1) * ngroups) / p.blocks_per_pair;
+    const int wave_off = wave_ * (64 * DVO_PX_PER_THREAD);
     const float wpar = (float)((p.scale1 != nullptr) ? student_t_lambda(p, pair, 0.0, false) : p.wparam[pair]);
     const float* rc_in = p.rcache + (size_t)pair * p.g.npix;
-    float acc = 0.0f;
-    for (int grp = 0; grp < p.groups_per_block; ++grp) {
-        const int seg = rec0 + grp * gstride;
+    float acc = 0.0f, cnt = 0.0f;
+    for (int grp = g_lo; grp < g_hi; ++grp) {
+        const int seg = grp * DVO_PX_PER_BLOCK + wave_off;
         if (seg >= count) break;
         float r[DVO_PX_PER_THREAD];
 #pragma unroll
@@ -1057,18 +1066,19 @@ __global__ __launch_bounds__(DVO_BLOCK) void k_scale_cached(const DvoReduceParam
             if (r[j] == r[j]) {
                 const float r2 = r[j] * r[j];
                 acc += r2 * (6.0f * fast_rcp(fmaf(r2, wpar, 5.0f)));
+                cnt += 1.0f;
             }
         }
     }
-    __shared__ double lds1[DVO_BLOCK / 64];
-    const double sw = wave_sum((double)acc);
-    if ((threadIdx.x & 63) == 0) lds1[threadIdx.x >> 6] = sw;
+    __shared__ double lds1[2][DVO_BLOCK / 64];
+    const double sw = wave_sum((double)acc), cw = wave_sum((double)cnt);
+    if ((threadIdx.x & 63) == 0) { lds1[0][threadIdx.x >> 6] = sw; lds1[1][threadIdx.x >> 6] = cw; }
     __syncthreads();
     if (p.scale_out != nullptr) {
-        if (threadIdx.x == 0) p.scale_out[(size_t)pair * p.blocks_per_pair + blk] = (lds1[0] + lds1[1]) + (lds1[2] + lds1[3]);
+        if (threadIdx.x == 0) p.scale_out[(size_t)pair * p.blocks_per_pair + blk] = (lds1[0][0] + lds1[0][1]) + (lds1[0][2] + lds1[0][3]);
     } else if (threadIdx.x < DVO_STRIDE) {
         double tot = 0.0;
-        if (threadIdx.x == 0) tot = (lds1[0] + lds1[1]) + (lds1[2] + lds1[3]);
+        if (threadIdx.x < 2) tot = (lds1[threadIdx.x][0] + lds1[threadIdx.x][1]) + (lds1[threadIdx.x][2] + lds1[threadIdx.x][3]);
         p.partials[((size_t)pair * p.blocks_per_pair + blk) * DVO_STRIDE + threadIdx.x] = tot;
     }
 }
@@ -1087,7 +1097,7 @@ static hipError_t launch_reduce_v(const DvoReduceParams& p, int weight_mode, int
         hipLaunchKernelGGL((k_reduce<VARIANT, 1, true, TAG, SKEW>), grid, block, 0, s, p);
     } else if (weight_mode == 0) {
         hipLaunchKernelGGL((k_reduce<VARIANT, 0, false, TAG, SKEW>), grid, block, 0, s, p);
-    } else if (weight_mode == 1) {
+    } else if (weight_mode == 1 || weight_mode == 3) {          // both Student-t forms weight with 6 / (5 + r^2 lambda)
         hipLaunchKernelGGL((k_reduce<VARIANT, 1, false, TAG, SKEW>), grid, block, 0, s, p);
     } else {
         hipLaunchKernelGGL((k_reduce<VARIANT, 2, false, TAG, SKEW>), grid, block, 0, s, p);
@@ -1564,7 +1574,7 @@ __global__ void k_level_begin(DvoPairState* st, int* active, double* wparam, int
     active[i] = 1;
     for (int k = 0; k < 4; ++k) st[i].oq[k] = st[i].lq[k];          // old = last_estimated_transform.copy()  (:154)
     for (int k = 0; k < 3; ++k) st[i].ot[k] = st[i].lt[k];
-    if (weight_mode == 1) wparam[i] = lambda0;                                     // t_weighter.py:23
+    if (weight_mode == 1 || weight_mode == 3) wparam[i] = lambda0;                 // t_weighter.py:23
     if (weight_mode == 2) wparam[i] = (st[i].lambda > 0.0) ? st[i].lambda : DVO_FLT_MAX;   // no scale yet: w = 1
 }
 
@@ -1585,11 +1595,14 @@ __device__ __forceinline__ void gn_control(const P& p, int phase, int pair, DvoP
                                            double* wparam, double* rec)
 {
     if (phase != 0) {
-        // Student-t scale pass k (weighter/t_weighter.py:24-32): lambda <- 1 / sum, stop when |d lambda| < 1e-3
+        // Student-t scale pass k (weighter/t_weighter.py:24-32): lambda <- 1 / scale, stop when lambda has settled.
+        //   weight_mode 1 (the reference): scale = SUM of the weighted r^2 (quirk Q3), |d lambda| < 1e-3 absolute
+        //   weight_mode 3 (proper):        scale = MEAN of the weighted r^2, |d lambda| <= 1e-3 lambda
         const double last = *wparam;
         if (st.pad == 0) {                       // pad: 1 once the IRLS loop has converged for this iteration
-            const double cur = 1.0 / rec[0];
-            if (fabs(cur - last) < 1e-3) st.pad = 1;
+            const double cur = (p.weight_mode == 3) ? rec[1] / rec[0] : 1.0 / rec[0];
+            const bool conv = (p.weight_mode == 3) ? (fabs(cur - last) <= 1e-3 * cur) : (fabs(cur - last) < 1e-3);
+            if (conv) { st.pad = 1; if (p.irls_done != nullptr) p.irls_done[pair] = 1; }
             *wparam = cur;
         }
         return;
@@ -1645,7 +1658,9 @@ __device__ __forceinline__ void gn_control(const P& p, int phase, int pair, DvoP
         if (st.increased > p.max_increased) stop = true;                                // :224
     }
     if (stop) { st.active = 0; *active = 0; }
-    if (p.weight_mode == 1) { *wparam = 1.0 / 25.0; st.pad = 0; }                       // next iteration restarts IRLS
+    if (p.weight_mode == 1) { *wparam = 1.0 / 25.0; st.pad = 0; }                       // next iteration restarts IRLS (t_weighter.py:23)
+    if (p.weight_mode == 3) st.pad = 0;                                                  // ... warm-started from this iteration's lambda
+    if ((p.weight_mode == 1 || p.weight_mode == 3) && p.irls_done != nullptr) p.irls_done[pair] = 0;
     if (p.weight_mode == 2) {
         const double sig = (n > 0.0) ? sqrt(rec[29] / n) : -1.0;
         st.lambda = (sig > 0.0) ? p.weight_param * sig : -1.0;
@@ -1758,6 +1773,7 @@ __global__ __launch_bounds__(DVO_SMALL_MAX_THREADS) void k_gn_small(const DvoSma
     __shared__ double rec_sh[DVO_STRIDE];
     __shared__ double wsum[DVO_SMALL_MAX_WAVES][DVO_STRIDE];
     __shared__ double scal[2][DVO_SMALL_MAX_WAVES];
+    __shared__ double scnt_sh[2][DVO_SMALL_MAX_WAVES];
     __shared__ float wbuf[DVO_SMALL_MAX_WAVES][8 * 65];
     const int pair = blockIdx.x, tid = threadIdx.x;
     const int lane_ = tid & 63, wave_ = tid >> 6, nwaves = (int)blockDim.x >> 6;
@@ -1786,7 +1802,7 @@ __global__ __launch_bounds__(DVO_SMALL_MAX_THREADS) void k_gn_small(const DvoSma
             active_sh = 1;
             for (int k = 0; k < 4; ++k) st.oq[k] = st.lq[k];
             for (int k = 0; k < 3; ++k) st.ot[k] = st.lt[k];
-            if (WMODE == 1) wpar_sh = p.lambda0;                                           // t_weighter.py:23
+            if (WMODE == 1) wpar_sh = p.lambda0;                                           // t_weighter.py:23 (both Student-t forms)
             if (WMODE == 2) wpar_sh = (st.lambda > 0.0) ? st.lambda : DVO_FLT_MAX;        // no scale yet: w = 1
         }
         __syncthreads();
@@ -1800,10 +1816,14 @@ __global__ __launch_bounds__(DVO_SMALL_MAX_THREADS) void k_gn_small(const DvoSma
             if constexpr (WMODE == 2) wpar = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint((float)wpar_sh)));
             if constexpr (WMODE == 1) {
                 // TDistributionWeighter.weight (weighter/t_weighter.py:21-34): lambda <- 1 / scale(lambda) until |d lambda| < 1e-3
-                double last = p.lambda0, cur = p.lambda0;
-                for (int pass = 0; pass < 50; ++pass) {
+                // student_t_mean (weight_mode 3, "proper"): scale = mean, relative tolerance, at most 4 passes, warm-started from the
+                // previous iteration's lambda; otherwise the reference's loop (sum, |d lambda| < 1e-3, at most 50 passes, from 1/25)
+                const bool mean = p.student_t_mean != 0;
+                const int max_pass = mean ? 4 : 50;
+                double last = mean ? wpar_sh : p.lambda0, cur = last;
+                for (int pass = 0; pass < max_pass; ++pass) {
                     const float lamf = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint((float)last)));
-                    float sacc = 0.0f;
+                    float sacc = 0.0f, scnt = 0.0f;
                     for (int seg = rec0; seg < count; seg += gstride) {          // wave-uniform bounds
                         float r[DVO_PX_PER_THREAD];
                         if (pass == 0 || rc_mine == nullptr) {
@@ -1846,19 +1866,21 @@ __global__ __launch_bounds__(DVO_SMALL_MAX_THREADS) void k_gn_small(const DvoSma
                             if (r[j] == r[j]) {
                                 const float r2 = r[j] * r[j];
                                 sacc += r2 * (6.0f * fast_rcp(fmaf(r2, lamf, 5.0f)));       // t_weighter.py:43-45, dof = 5
+                                scnt += 1.0f;
                             }
                         }
                     }
-                    const double sw = wave_sum((double)sacc);
-                    if (lane_ == 0) scal[pass & 1][wave_] = sw;
+                    const double sw = wave_sum((double)sacc), cw = wave_sum((double)scnt);
+                    if (lane_ == 0) { scal[pass & 1][wave_] = sw; scnt_sh[pass & 1][wave_] = cw; }
                     __syncthreads();
-                    double S = 0.0;
-                    for (int w = 0; w < nwaves; ++w) S += scal[pass & 1][w];      // every thread, same order: same S
-                    cur = 1.0 / S;
-                    if (fabs(cur - last) < 1e-3) break;                             // uniform
+                    double S = 0.0, N = 0.0;
+                    for (int w = 0; w < nwaves; ++w) { S += scal[pass & 1][w]; N += scnt_sh[pass & 1][w]; }   // every thread, same order
+                    cur = mean ? N / S : 1.0 / S;
+                    if (mean ? (fabs(cur - last) <= 1e-3 * cur) : (fabs(cur - last) < 1e-3)) break;      // uniform
                     last = cur;
                 }
                 wpar = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint((float)cur)));
+                if (mean && tid == 0) wpar_sh = cur;          // (every thread read wpar_sh before the first barrier of the loop)
             }
 
             float acc[DVO_NACC];
@@ -1932,7 +1954,7 @@ hipError_t dvo_launch_gn_small(const DvoSmallParams& p, int variant, int threads
 #define DVO_SMALL_W(V, S)                                                     \
     do {                                                                      \
         if (p.weight_mode == 0) DVO_SMALL_LAUNCH(V, 0, S);                    \
-        else if (p.weight_mode == 1) DVO_SMALL_LAUNCH(V, 1, S);               \
+        else if (p.weight_mode == 1 || p.weight_mode == 3) DVO_SMALL_LAUNCH(V, 1, S);   \
         else DVO_SMALL_LAUNCH(V, 2, S);                                       \
     } while (0)
     if (variant == 0) { if (skew) DVO_SMALL_W(0, true); else DVO_SMALL_W(0, false); }

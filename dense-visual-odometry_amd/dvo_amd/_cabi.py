@@ -17,7 +17,7 @@ TRACE_STRIDE = 50
 MAX_LEVELS = 8
 
 VARIANT_V1, VARIANT_V2, VARIANT_V3 = 0, 1, 2
-WEIGHT_NONE, WEIGHT_STUDENT_T, WEIGHT_HUBER = 0, 1, 2
+WEIGHT_NONE, WEIGHT_STUDENT_T, WEIGHT_HUBER, WEIGHT_STUDENT_T_MEAN = 0, 1, 2, 3
 
 import os as _os
 
@@ -58,6 +58,8 @@ SIGNATURES = {
                                        C.c_void_p, C.c_void_p]),
     "dvo_weighted_r2_sum": (C.c_int, [_ctx, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
                                       C.c_void_p, C.c_void_p]),
+    "dvo_weighted_r2_stats": (C.c_int, [_ctx, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
+                                        C.c_void_p, C.c_void_p]),
     "dvo_residuals_jacobian": (C.c_int, [_ctx, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p,
                                          C.c_void_p, C.c_void_p, C.c_void_p]),
     "dvo_solve_batch": (C.c_int, [_ctx, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_int,
@@ -291,6 +293,20 @@ class HipContext:
         out = np.empty(n, dtype=np.float64)
         self._check(self._lib.dvo_weighted_r2_sum(self._h, level, n, _ptr(ps), _ptr(cs), _ptr(Tm), variant, _ptr(lm),
                                                   _ptr(out)))
+        return out
+
+    def weighted_r2_stats(self, level: int, prev_slots, cur_slots, T, lam, variant: int = VARIANT_V1) -> np.ndarray:
+        """-> (n_pairs, 2): the Student-t scale sum and the number of residuals it ran over."""
+        ps = _as(prev_slots, np.int32)
+        cs = _as(cur_slots, np.int32)
+        n = ps.shape[0]
+        Tm = _as(T, np.float32).reshape(n, -1)
+        if Tm.shape[1] == 16:
+            Tm = np.ascontiguousarray(Tm[:, :12])
+        lm = _as(lam, np.float64, (n,))
+        out = np.empty((n, 2), dtype=np.float64)
+        self._check(self._lib.dvo_weighted_r2_stats(self._h, level, n, _ptr(ps), _ptr(cs), _ptr(Tm), variant, _ptr(lm),
+                                                    _ptr(out)))
         return out
 
     def residuals_jacobian(self, level: int, prev_slot: int, cur_slot: int, T: np.ndarray, variant: int = VARIANT_V1,

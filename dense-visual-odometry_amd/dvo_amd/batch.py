@@ -16,7 +16,8 @@ import numpy as np
 
 from . import _cabi
 
-_WEIGHTS = {"none": _cabi.WEIGHT_NONE, "student_t_reference": _cabi.WEIGHT_STUDENT_T, "huber": _cabi.WEIGHT_HUBER}
+_WEIGHTS = {"none": _cabi.WEIGHT_NONE, "student_t_reference": _cabi.WEIGHT_STUDENT_T, "huber": _cabi.WEIGHT_HUBER,
+            "student_t": _cabi.WEIGHT_STUDENT_T_MEAN}
 
 
 class BatchAligner:

@@ -39,7 +39,10 @@ class ImagePyramidError(Exception):
 
 
 _VARIANTS = {"v1": _cabi.VARIANT_V1, "v2": _cabi.VARIANT_V2, "v3": _cabi.VARIANT_V3}
-_WEIGHTS = {"none": _cabi.WEIGHT_NONE, "student_t_reference": _cabi.WEIGHT_STUDENT_T, "huber": _cabi.WEIGHT_HUBER}
+# "student_t_reference": the reference's weighter as written (scale = SUM, quirk Q3: weights ~ 1.2 for every pixel);
+# "student_t": the same weight with the scale taken as the MEAN (build-defined, what the reference intends); "huber": new
+_WEIGHTS = {"none": _cabi.WEIGHT_NONE, "student_t_reference": _cabi.WEIGHT_STUDENT_T, "huber": _cabi.WEIGHT_HUBER,
+            "student_t": _cabi.WEIGHT_STUDENT_T_MEAN}
 
 
 class DevicePyramid:
@@ -117,6 +120,7 @@ class RobustDVOHIP:
         self._curr_depth_image_pyr = None
         self._prev_depth_image_pyr = None
         self._huber_sigma = None
+        self._t_lambda = 1.0 / 25.0
         self.last_iterations = 0
 
     # -- reference-facing properties ---------------------------------------------------------------------
@@ -237,6 +241,10 @@ class RobustDVOHIP:
         if self._weighting == "student_t_reference":
             lam = self._student_t_lambda(level, T)
             rec = self._ctx.normal_equations(level, ps, cs, T, self._variant, _cabi.WEIGHT_STUDENT_T, [lam])[0]
+        elif self._weighting == "student_t":
+            self._t_lambda = self._student_t_mean_lambda(level, T, self._t_lambda)
+            rec = self._ctx.normal_equations(level, ps, cs, T, self._variant, _cabi.WEIGHT_STUDENT_T_MEAN,
+                                             [self._t_lambda])[0]
         elif self._weighting == "huber":
             k = np.finfo(np.float32).max if self._huber_sigma is None else self._huber_k * self._huber_sigma
             rec = self._ctx.normal_equations(level, ps, cs, T, self._variant, _cabi.WEIGHT_HUBER, [k])[0]
@@ -259,6 +267,18 @@ class RobustDVOHIP:
                                                      self._variant)[0])
             cur = 1.0 / sigma2 if sigma2 != 0.0 else float("inf")
             if abs(cur - last) < tol:
+                break
+            last = cur
+        return cur
+
+    def _student_t_mean_lambda(self, level: int, T: np.ndarray, lam_init: float, rel_tol: float = 1e-3,
+                               max_passes: int = 4) -> float:
+        """IRLS of the mean-based Student-t scale (oracle.student_t_mean_weights), scale passes on the device."""
+        last = cur = float(lam_init)
+        for _ in range(max_passes):
+            s, n = self._ctx.weighted_r2_stats(level, [self._prev_slot], [self._cur_slot], T, [last], self._variant)[0]
+            cur = (n / s) if s != 0.0 else float("inf")
+            if abs(cur - last) <= rel_tol * cur:
                 break
             last = cur
         return cur
@@ -286,6 +306,7 @@ class RobustDVOHIP:
                 old = self._last_estimated_transform.copy()                       # base_robust_dvo.py:154
             err_prev = np.finfo("float32").max
             err_increased_count = 0
+            self._t_lambda = 1.0 / 25.0                     # "student_t": every level starts from initial_sigma = 5
             self._setup(level=level)
             for i in range(self._max_iter):
                 H, b, err, n = self.compute_normal_equations(estimate=estimate, level=level)

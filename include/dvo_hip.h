@@ -65,7 +65,11 @@ typedef enum dvo_weight_mode {
     DVO_WEIGHT_NONE = 0,       /* use_weighter=False: w = 1 */
     DVO_WEIGHT_STUDENT_T = 1,  /* w = 6 / (5 + r^2 * lambda); weight_param[pair] = lambda
                                   (weighter/t_weighter.py:34) */
-    DVO_WEIGHT_HUBER = 2       /* build-defined: w = min(1, k/|r|); weight_param[pair] = k (grey levels) */
+    DVO_WEIGHT_HUBER = 2,      /* build-defined: w = min(1, k/|r|); weight_param[pair] = k (grey levels) */
+    DVO_WEIGHT_STUDENT_T_MEAN = 3  /* build-defined "proper" Student-t: the same weight, but the scale is the MEAN of the weighted
+                                  r^2 (what t_weighter.py:41-45 intends; the reference's np.mean of a 1-element row is a sum, quirk
+                                  Q3), IRLS to |d lambda| <= 1e-3 lambda, at most 4 passes per Gauss-Newton iteration, each iteration
+                                  warm-started from the previous one's lambda.  weight_param[pair] = lambda. */
 } dvo_weight_mode;
 
 #define DVO_NE_STRIDE 32
@@ -156,6 +160,11 @@ int dvo_normal_equations(dvo_ctx* ctx, int level, int n_pairs, const int* prev_s
 int dvo_weighted_r2_sum(dvo_ctx* ctx, int level, int n_pairs, const int* prev_slot, const int* cur_slot,
                         const float* T, int variant, const double* lambda, double* out);
 
+/* The same pass returning both the sum and the number of residuals it ran over (depth-valid and in bounds):
+ * stats[2 * pair] = sum, stats[2 * pair + 1] = count; the mean-based scale of DVO_WEIGHT_STUDENT_T_MEAN is sum / count. */
+int dvo_weighted_r2_stats(dvo_ctx* ctx, int level, int n_pairs, const int* prev_slot, const int* cur_slot,
+                          const float* T, int variant, const double* lambda, double* stats);
+
 /* Dense outputs with the return contract of compute_residuals_and_jacobian (API parity / debugging):
  * r [h*w] (0 where invalid), J [h*w][6], valid [h*w] (depth != 0 AND warped point in bounds),
  * uv [h*w][2] warped coordinates (NaN where depth == 0).  Any output pointer may be NULL. */
@@ -163,8 +172,13 @@ int dvo_residuals_jacobian(dvo_ctx* ctx, int level, int prev_slot, int cur_slot,
                            float* r, float* J, uint8_t* valid, float* uv);
 
 /* Whole coarse-to-fine Gauss-Newton solve of n_pairs frame pairs on the device (BaseRobustDVO._step,
- * base_robust_dvo.py:137-236, sigma prior off): per iteration one reduction launch and one tiny
- * solve/update launch per batch, no host round trip; stop rules evaluated per pair on the device.
+ * base_robust_dvo.py:137-236): no host round trip; stop rules evaluated per pair on the device.  Pyramid levels of at most
+ * 160 x 120 pixels run in one persistent launch (a workgroup per pair does all their iterations); finer levels take one
+ * reduction launch and one control launch per iteration.
+ * Student-t IRLS (weighter/t_weighter.py:21-34): on the persistent levels the reference's loop as written (until
+ * |d lambda| < 1e-3, at most 50 passes); on the finer levels DVO_WEIGHT_STUDENT_T runs the TWO scale passes that loop takes
+ * whenever the summed scale exceeds 1000 (any image with more than a few hundred non-zero residuals: lambda is then below
+ * 1e-3 after the first pass, so the second difference is too) and DVO_WEIGHT_STUDENT_T_MEAN its at most four.
  *   T_init  n_pairs x 12 or NULL (identity)          T_out   n_pairs x 12
  *   xi_out  n_pairs x 6 float64 log of the estimate (may be NULL)
  *   iters_out n_pairs (total GN iterations run, may be NULL)   err_out n_pairs (last accepted error, may be NULL) */

@@ -356,6 +356,25 @@ def student_t_weights(r: np.ndarray, dof: int = 5, initial_sigma: float = 5.0, t
     return (dof + 1) / (dof + r2 * cur), cur
 
 
+def student_t_mean_weights(r: np.ndarray, lam_init: float, dof: int = 5, rel_tol: float = 1e-3, max_passes: int = 4):
+    """Build-defined "proper" Student-t weighter (no reference counterpart beyond its intent; parity unpinned): the loop of
+    weighter/t_weighter.py:21-34 with the scale taken as the MEAN of the weighted squared residuals (what :41-45 means to
+    compute; as written `np.mean` runs over a 1-element row, i.e. it is a sum — quirk Q3), a relative stop rule
+    |d lambda| <= rel_tol * lambda, at most `max_passes` passes, started from `lam_init` (the caller warm-starts it from
+    the previous Gauss-Newton iteration).  Returns (w float64, lambda)."""
+    r2 = (np.asarray(r, dtype=np.float32) * np.asarray(r, dtype=np.float32)).astype(np.float64).reshape(-1)
+    n = r2.shape[0]
+    last = float(lam_init)
+    cur = last
+    for _ in range(max_passes):
+        sigma2 = student_t_scale_sum(r2, last, dof) / n
+        cur = 1.0 / sigma2
+        if abs(cur - last) <= rel_tol * cur:
+            break
+        last = cur
+    return (dof + 1) / (dof + r2 * cur), cur
+
+
 def huber_weights(r: np.ndarray, k: float):
     """Build-defined Huber weight w = min(1, k/|r|) (the reference has none; parity unpinned)."""
     a = np.abs(np.asarray(r, dtype=np.float64).reshape(-1))
@@ -591,6 +610,7 @@ def gauss_newton(gray_prev, depth_prev, gray_cur, K, depth_scale, levels: int, m
         weighting = "student_t_reference" if use_weighter else "none"
     sigma_prev = None
     for level in range(levels - 1, -1, -1):
+        lam_t = 1.0 / 25.0                              # "student_t": every level starts from initial_sigma = 5 (t_weighter.py:11-15)
         lv = PairLevel(gp[level], dp[level], gc[level], level_intrinsics(K, level), depth_scale)
         err_prev = float(np.finfo("float32").max)
         increased = 0
@@ -603,6 +623,8 @@ def gauss_newton(gray_prev, depth_prev, gray_cur, K, depth_scale, levels: int, m
             n = r.shape[0]
             if weighting == "student_t_reference":
                 w, _ = student_t_weights(r)
+            elif weighting == "student_t":
+                w, lam_t = student_t_mean_weights(r, lam_t)          # warm-started from the previous iteration of this level
             elif weighting == "huber":
                 # build-defined (no reference counterpart): k = huber_k * sigma of the PREVIOUS evaluated
                 # iteration of this pair (carried across levels); the very first iteration is unweighted

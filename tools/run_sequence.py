@@ -31,7 +31,7 @@ def main():
     ap.add_argument("--size", type=int, default=None)
     ap.add_argument("--levels", type=int, default=4)
     ap.add_argument("--iterations", type=int, default=10)
-    ap.add_argument("--weighting", default="none", choices=["none", "student_t_reference", "huber"])
+    ap.add_argument("--weighting", default="none", choices=["none", "student_t_reference", "student_t", "huber"])
     ap.add_argument("--window", type=int, default=128, help="frames per batched solve")
     ap.add_argument("--camera", type=Path, default=None, help="camera_intrinsics.yaml (TUM mode; default fr1)")
     ap.add_argument("--out", type=Path, default=ROOT / "gpurun_out" / "sequence")
