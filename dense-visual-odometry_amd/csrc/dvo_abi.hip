@@ -682,6 +682,96 @@ int dvo_upload_frames(dvo_ctx* ctx, int n_frames, const int* slots, const uint8_
     return DVO_OK;
 }
 
+// largest raw depth the clamp of core/base_dense_visual_odometry.py:59 keeps: (double)d * depth_scale > max_distance is
+// monotonic in d, so the per-pixel float64 product becomes one integer compare on the device, exactly
+static unsigned depth_clamp_threshold(double depth_scale, double max_distance)
+{
+    unsigned lo = 0, hi = 65535;                   // invariant: every d <= lo is kept (d = 0 always is)
+    if (!((double)hi * depth_scale > max_distance)) return hi;
+    while (lo + 1 < hi) {
+        const unsigned mid = (lo + hi) / 2;
+        if ((double)mid * depth_scale > max_distance) hi = mid; else lo = mid;
+    }
+    return lo;
+}
+
+int dvo_upload_frames_bgr_device(dvo_ctx* ctx, int n_frames, const int* slots, const void* d_bgr, const void* d_depth,
+                                 int w, int h, int levels, double max_distance)
+{
+    if (!ctx) return DVO_ERR_INVALID_ARG;
+    if (!slots || !d_bgr || !d_depth) return fail(ctx, DVO_ERR_INVALID_ARG, "dvo_upload_frames_bgr_device: null argument");
+    if (n_frames < 1 || n_frames > ctx->n_slots) return fail(ctx, DVO_ERR_INVALID_ARG, "n_frames %d outside [1,%d]", n_frames, ctx->n_slots);
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    for (int i = 0; i < n_frames; ++i) {
+        for (int j = 0; j < i; ++j)
+            if (slots[j] == slots[i]) return fail(ctx, DVO_ERR_INVALID_ARG, "slot %d listed twice", slots[i]);
+        int rc = prepare_slot(ctx, slots[i], w, h, levels);
+        if (rc) return rc;
+    }
+    DvoBatchIngestParams p;
+    p.slots = ctx->d_slots;
+    p.slot_stride = ctx->slot_stride;
+    p.slot_ids = ctx->d_frame_slots;
+    p.src_gray = nullptr;                        // level 0 is written into the slots by the colour kernel
+    p.src_depth = nullptr;
+    p.n_frames = n_frames;
+    p.levels = levels;
+    p.depth_scale = ctx->depth_scale;
+    p.list_count = ctx->d_list_count;
+    p.seg_counts = ctx->d_seg_counts;
+    p.allow_fused = ctx->knobs.ingest_unfused ? 0 : 1;
+    level_geometry(w, h, levels, p.g, nullptr);
+    {
+        int rc = stage_frame_slots(ctx, slots, n_frames);
+        if (rc) return rc;
+    }
+    HIP_TRY(ctx, dvo_launch_batch_bgr_ingest(p, static_cast<const uint8_t*>(d_bgr), static_cast<const uint16_t*>(d_depth),
+                                             depth_clamp_threshold(ctx->depth_scale, max_distance), ctx->stream));
+    HIP_TRY(ctx, dvo_launch_batch_ingest(p, ctx->stream));
+    for (int i = 0; i < n_frames; ++i) ctx->slots[slots[i]].ready = true;
+    return DVO_OK;
+}
+
+int dvo_upload_frames_bgr(dvo_ctx* ctx, int n_frames, const int* slots, const uint8_t* bgr, const uint16_t* depth,
+                          int w, int h, int levels, double max_distance)
+{
+    if (!ctx) return DVO_ERR_INVALID_ARG;
+    if (!slots || !bgr || !depth) return fail(ctx, DVO_ERR_INVALID_ARG, "dvo_upload_frames_bgr: null argument");
+    if (n_frames < 1 || n_frames > ctx->n_slots) return fail(ctx, DVO_ERR_INVALID_ARG, "n_frames %d outside [1,%d]", n_frames, ctx->n_slots);
+    if (w <= 0 || h <= 0 || w > ctx->max_w || h > ctx->max_h) return fail(ctx, DVO_ERR_INVALID_ARG, "image %dx%d outside the ctx maximum", w, h);
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    // one device staging area for the whole batch (grown on demand): colour (3 B/px) then depth (2 B/px), two large copies
+    const size_t npx = (size_t)w * h, cbytes = align_up(npx * n_frames * 3, 256), need = cbytes + npx * n_frames * 2 + 256;
+    if (need > ctx->batch_stage_bytes) {
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        if (ctx->upload_peer) HIP_TRY(ctx, hipStreamSynchronize(ctx->upload_peer->copy_stream));
+        if (ctx->d_batch_stage) (void)hipFree(ctx->d_batch_stage);
+        ctx->d_batch_stage = nullptr;
+        ctx->batch_stage_bytes = 0;
+        HIP_TRY(ctx, hipMalloc((void**)&ctx->d_batch_stage, need));
+        ctx->batch_stage_bytes = need;
+    }
+    uint8_t* sc = ctx->d_batch_stage;
+    uint16_t* sd = reinterpret_cast<uint16_t*>(ctx->d_batch_stage + cbytes);
+    if (ctx->upload_peer == nullptr) {
+        HIP_TRY(ctx, hipMemcpyAsync(sc, bgr, npx * n_frames * 3, hipMemcpyHostToDevice, ctx->stream));
+        HIP_TRY(ctx, hipMemcpyAsync(sd, depth, npx * n_frames * 2, hipMemcpyHostToDevice, ctx->stream));
+        return dvo_upload_frames_bgr_device(ctx, n_frames, slots, sc, sd, w, h, levels, max_distance);
+    }
+    // copies on the shared in-order copy stream, kernels wait by event (see dvo_upload_frames)
+    hipStream_t cs = ctx->upload_peer->copy_stream;
+    if (ctx->ingested_recorded) HIP_TRY(ctx, hipStreamWaitEvent(cs, ctx->ev_ingested, 0));
+    HIP_TRY(ctx, hipMemcpyAsync(sc, bgr, npx * n_frames * 3, hipMemcpyHostToDevice, cs));
+    HIP_TRY(ctx, hipMemcpyAsync(sd, depth, npx * n_frames * 2, hipMemcpyHostToDevice, cs));
+    HIP_TRY(ctx, hipEventRecord(ctx->ev_uploaded, cs));
+    HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_uploaded, 0));
+    int rc = dvo_upload_frames_bgr_device(ctx, n_frames, slots, sc, sd, w, h, levels, max_distance);
+    if (rc) return rc;
+    HIP_TRY(ctx, hipEventRecord(ctx->ev_ingested, ctx->stream));
+    ctx->ingested_recorded = true;
+    return DVO_OK;
+}
+
 int dvo_set_upload_peer(dvo_ctx* ctx, dvo_ctx* peer)
 {
     if (!ctx) return DVO_ERR_INVALID_ARG;

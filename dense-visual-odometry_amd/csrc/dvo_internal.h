@@ -172,6 +172,8 @@ struct DvoBatchIngestParams {
 hipError_t dvo_launch_bgr_ingest(const uint8_t* bgr, const uint16_t* depth_in, int w, int h, uint8_t* gray,
                                  uint16_t* depth_out, double depth_scale, double max_distance, hipStream_t s);
 hipError_t dvo_launch_batch_ingest(const DvoBatchIngestParams& p, hipStream_t s);
+hipError_t dvo_launch_batch_bgr_ingest(const DvoBatchIngestParams& p, const uint8_t* bgr, const uint16_t* depth_in, unsigned d_max,
+                                       hipStream_t s);
 hipError_t dvo_launch_unpack(const uint32_t* packed, int w, int h, int pitch, int16_t* gx, int16_t* gy, hipStream_t s);
 hipError_t dvo_launch_reduce(const DvoReduceParams& p, int variant, int weight_mode, int scale_pass, hipStream_t s);
 hipError_t dvo_launch_scale_cached(const DvoReduceParams& p, hipStream_t s);

@@ -85,6 +85,61 @@ hipError_t dvo_launch_bgr_ingest(const uint8_t* bgr, const uint16_t* depth_in, i
     return hipGetLastError();
 }
 
+// Batched colour ingest: n frames of BGR u8 [n][h][w][3] + depth u16 [n][h][w] (device) -> gray / clamped depth written straight
+// into the level-0 planes of the listed slots (blockIdx.z = frame), 4 pixels per lane: 12 + 8 bytes in, 4 + 8 bytes out.
+// The depth clamp `depth * depth_scale > max_distance -> 0` (core/base_dense_visual_odometry.py:59, a float64 product) is
+// monotonic in the integer depth, so the host turns it into the exact integer threshold d_max (largest depth that is kept).
+__global__ __launch_bounds__(DVO_BLOCK) void k_batch_bgr_ingest(const DvoBatchIngestParams p, const uint8_t* __restrict__ bgr,
+                                                                const uint16_t* __restrict__ depth_in, unsigned d_max)
+{
+    const int f = blockIdx.z;
+    uint8_t* slot = p.slots + (size_t)p.slot_ids[f] * p.slot_stride;
+    const size_t n = (size_t)p.g[0].npix;
+    const size_t i = ((size_t)blockIdx.x * DVO_BLOCK + threadIdx.x) * 4;
+    if (i >= n) return;
+    const uint8_t* sb = bgr + ((size_t)f * n + i) * 3;
+    const uint16_t* sd = depth_in + (size_t)f * n + i;
+    uint8_t* dg = slot + p.g[0].off_gray + i;
+    uint16_t* dd = reinterpret_cast<uint16_t*>(slot + p.g[0].off_depth) + i;
+    unsigned c[12], d[4];
+    const bool full = (i + 4 <= n);
+    if (full && ((reinterpret_cast<uintptr_t>(sb) & 3u) == 0) && ((reinterpret_cast<uintptr_t>(sd) & 7u) == 0)) {
+        const uint32_t a0 = reinterpret_cast<const uint32_t*>(sb)[0], a1 = reinterpret_cast<const uint32_t*>(sb)[1],
+                       a2 = reinterpret_cast<const uint32_t*>(sb)[2];
+        const uint2 dv = *reinterpret_cast<const uint2*>(sd);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { c[k] = (a0 >> (8 * k)) & 0xffu; c[4 + k] = (a1 >> (8 * k)) & 0xffu; c[8 + k] = (a2 >> (8 * k)) & 0xffu; }
+        d[0] = dv.x & 0xffffu; d[1] = dv.x >> 16; d[2] = dv.y & 0xffffu; d[3] = dv.y >> 16;
+    } else {
+#pragma unroll
+        for (int k = 0; k < 12; ++k) c[k] = (i + k / 3 < n) ? sb[k] : 0u;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) d[k] = (i + k < n) ? sd[k] : 0u;
+    }
+    unsigned g4 = 0u;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const unsigned gv = (c[3 * k] * 3735u + c[3 * k + 1] * 19235u + c[3 * k + 2] * 9798u + (1u << 14)) >> 15;     // as k_bgr_ingest
+        g4 |= gv << (8 * k);
+        d[k] = (d[k] > d_max) ? 0u : d[k];
+    }
+    if (full && ((reinterpret_cast<uintptr_t>(dg) & 3u) == 0) && ((reinterpret_cast<uintptr_t>(dd) & 7u) == 0)) {
+        *reinterpret_cast<uint32_t*>(dg) = g4;
+        *reinterpret_cast<uint2*>(dd) = make_uint2(d[0] | (d[1] << 16), d[2] | (d[3] << 16));
+    } else {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) if (i + k < n) { dg[k] = (uint8_t)(g4 >> (8 * k)); dd[k] = (uint16_t)d[k]; }
+    }
+}
+
+hipError_t dvo_launch_batch_bgr_ingest(const DvoBatchIngestParams& p, const uint8_t* bgr, const uint16_t* depth_in, unsigned d_max,
+                                       hipStream_t s)
+{
+    const unsigned nb = (unsigned)(((size_t)p.g[0].npix + DVO_BLOCK * 4 - 1) / (DVO_BLOCK * 4));
+    hipLaunchKernelGGL(k_batch_bgr_ingest, dim3(nb, 1, (unsigned)p.n_frames), dim3(DVO_BLOCK), 0, s, p, bgr, depth_in, d_max);
+    return hipGetLastError();
+}
+
 // ================================================================================================
 // Batched frame ingest: the same K1/K2 arithmetic for n frames per launch (blockIdx.z = frame), so a
 // whole batch of frames costs 3 launches per pyramid level instead of 3 per level per frame.

@@ -51,6 +51,9 @@ SIGNATURES = {
     "dvo_host_alloc": (C.c_int, [C.c_size_t, C.POINTER(C.c_void_p)]),
     "dvo_host_free": (C.c_int, [C.c_void_p]),
     "dvo_upload_frame_bgr": (C.c_int, [_ctx, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_double]),
+    "dvo_upload_frames_bgr": (C.c_int, [_ctx, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_double]),
+    "dvo_upload_frames_bgr_device": (C.c_int, [_ctx, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
+                                               C.c_double]),
     "dvo_download_level": (C.c_int, [_ctx, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "dvo_slot_info": (C.c_int, [_ctx, C.c_int, _c_int_p, _c_int_p, _c_int_p]),
     "dvo_download_points": (C.c_int, [_ctx, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, _c_int_p]),
@@ -220,6 +223,24 @@ class HipContext:
             raise ValueError("gray/depth must be [n][h][w] arrays matching the slot list")
         self._keepalive = (g, d)
         self._check(self._lib.dvo_upload_frames(self._h, sl.shape[0], _ptr(sl), _ptr(g), _ptr(d), g.shape[2], g.shape[1], levels))
+
+    def upload_frames_bgr(self, slots, bgr: np.ndarray, depth: np.ndarray, levels: int, max_distance: float = 5.0):
+        """n colour frames from contiguous host arrays [n][h][w][3] (BGR u8) / [n][h][w] (u16 depth): two large copies, BGR->gray
+        and the depth clamp on the device.  Asynchronous for page-locked arrays (`pinned_array`)."""
+        sl = _as(slots, np.int32)
+        c = np.ascontiguousarray(bgr, dtype=np.uint8)
+        d = np.ascontiguousarray(depth, dtype=np.uint16)
+        if c.ndim != 4 or c.shape[3] != 3 or c.shape[:3] != d.shape or c.shape[0] != sl.shape[0]:
+            raise ValueError("bgr must be [n][h][w][3] and depth [n][h][w], matching the slot list")
+        self._keepalive = (c, d)
+        self._check(self._lib.dvo_upload_frames_bgr(self._h, sl.shape[0], _ptr(sl), _ptr(c), _ptr(d), c.shape[2], c.shape[1],
+                                                    levels, float(max_distance)))
+
+    def upload_frames_bgr_device(self, slots, d_bgr_ptr: int, d_depth_ptr: int, w: int, h: int, levels: int,
+                                 max_distance: float = 5.0):
+        sl = _as(slots, np.int32)
+        self._check(self._lib.dvo_upload_frames_bgr_device(self._h, sl.shape[0], _ptr(sl), C.c_void_p(d_bgr_ptr),
+                                                           C.c_void_p(d_depth_ptr), w, h, levels, float(max_distance)))
 
     def upload_frame_bgr(self, slot: int, bgr: np.ndarray, depth: np.ndarray, levels: int, max_distance: float):
         c = _as(bgr, np.uint8)

@@ -62,6 +62,14 @@ class BatchAligner:
             raise ValueError("n_frames must be in [2, {}]".format(self.max_pairs + 1))
         self.ctx.upload_frames(self._slots[:n], gray, depth, self.levels)
 
+    def ingest_host_bgr(self, bgr: np.ndarray, depth: np.ndarray, max_distance: float = 5.0):
+        """[n][h][w][3] BGR + [n][h][w] depth host arrays -> slots 0..n-1: batched upload, colour conversion and depth clamp
+        (core/base_dense_visual_odometry.py:58-59) on the device."""
+        n = bgr.shape[0]
+        if not (2 <= n <= self.max_pairs + 1):
+            raise ValueError("n_frames must be in [2, {}]".format(self.max_pairs + 1))
+        self.ctx.upload_frames_bgr(self._slots[:n], bgr, depth, self.levels, max_distance)
+
     def solve_enqueue(self, n_frames: int, T_init: Optional[np.ndarray] = None):
         prev = self._slots[:n_frames - 1]
         self.ctx.solve_batch_enqueue(prev, prev + 1, self.levels, self.max_iterations, self.tolerance,
@@ -129,6 +137,16 @@ class StreamedAligner:
         sl = self._slices(n_frames)
         for a, lo, hi in sl:                    # copies queue up on the shared copy stream in this order; the kernels
             a.ingest_host(gray[lo:hi + 1], depth[lo:hi + 1])      # of a slice start behind its own copies only
+            a.solve_enqueue(hi - lo + 1)
+        res = [a.solve_fetch(hi - lo + 1) for a, lo, hi in sl]
+        return {k: np.concatenate([r[k] for r in res], axis=0) for k in res[0]}
+
+    def align_host_bgr(self, bgr: np.ndarray, depth: np.ndarray, max_distance: float = 5.0):
+        """Colour host frames [n][h][w][3] + depth [n][h][w] (ideally page-locked): as align_host, conversion on the device."""
+        n_frames = bgr.shape[0]
+        sl = self._slices(n_frames)
+        for a, lo, hi in sl:
+            a.ingest_host_bgr(bgr[lo:hi + 1], depth[lo:hi + 1], max_distance)
             a.solve_enqueue(hi - lo + 1)
         res = [a.solve_fetch(hi - lo + 1) for a, lo, hi in sl]
         return {k: np.concatenate([r[k] for r in res], axis=0) for k in res[0]}

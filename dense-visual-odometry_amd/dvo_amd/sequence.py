@@ -1,0 +1,183 @@
+"""Sequence front end of the batched aligner: background frame decoding into page-locked windows, windowed batched
+alignment, and the report files of the reference's CLI harness.
+
+Counterparts in the reference (src/test_dvo.py): the loaders hold every decoded frame of the sequence in RAM before the
+first `step` (:180-191); `main` steps frame by frame (:298-321) and writes `report.json` — lists of the 6-vector logs of
+every pose / transform and the per-frame translational errors, plus the loader's additional info — and, for TUM data, the
+trajectory as `timestamp tx ty tz qx qy qz qw` (:323-345).  Here decoding runs in a thread one window ahead of the GPU,
+a window of frames goes up with one batched upload (`dvo_upload_frames` / `dvo_upload_frames_bgr`) and all its pairs are
+aligned in one device-side solve; the report keeps the reference's keys and adds the 4x4 forms and ATE / RPE.
+"""
+from __future__ import annotations
+
+import json
+import queue
+import threading
+import time
+from pathlib import Path
+from typing import Callable, Iterable, Iterator, List, Optional, Tuple
+
+import numpy as np
+
+from .lie import Se3
+from .batch import compose_trajectory
+
+
+class FrameWindows:
+    """Iterates over windows of consecutive frames of a sequence, decoded by a background thread into a small ring of
+    window buffers (page-locked when `alloc` is `_cabi.pinned_array`).  Consecutive windows share one frame: window k holds
+    frames [k*W, k*W + W] (W pairs), so every pair of the sequence appears in exactly one window.
+
+    `frames` yields (image, depth) with image HxW (gray u8) or HxWx3 (BGR u8) and depth HxW u16.  Each item of the
+    iteration is (image_window, depth_window, n_frames_in_window): views into a ring slot that stay valid until `depth`
+    further windows have been requested (`ring` = 3 by default: one being aligned, one uploaded, one being filled)."""
+
+    def __init__(self, frames: Iterable[Tuple[np.ndarray, np.ndarray]], window_pairs: int,
+                 alloc: Callable = None, ring: int = 3):
+        if window_pairs < 1 or ring < 2:
+            raise ValueError("window_pairs >= 1 and ring >= 2 required")
+        self._frames = iter(frames)
+        self._w = window_pairs
+        self._alloc = alloc or (lambda shape, dtype: np.empty(shape, dtype=dtype))
+        self._ring = ring
+        self._q: "queue.Queue" = queue.Queue(maxsize=ring - 1)
+        self._free: "queue.Queue" = queue.Queue()
+        self._err: Optional[BaseException] = None
+        self._thread = threading.Thread(target=self._fill, name="dvo-frame-decoder", daemon=True)
+        self._bufs: List[Tuple[np.ndarray, np.ndarray]] = []
+        self._started = False
+        self._stop = False
+        self.decode_seconds = 0.0
+
+    def _make_buffers(self, img, depth):
+        shape = (self._w + 1,) + tuple(img.shape)
+        for _ in range(self._ring):
+            self._bufs.append((self._alloc(shape, np.uint8), self._alloc((self._w + 1,) + tuple(depth.shape), np.uint16)))
+        for i in range(self._ring):
+            self._free.put(i)
+
+    def _fill(self):
+        try:
+            carry = None
+            done = False
+            while not done and not self._stop:
+                t0 = time.perf_counter()
+                items = [] if carry is None else [carry]
+                while len(items) < self._w + 1:
+                    try:
+                        items.append(next(self._frames))
+                    except StopIteration:
+                        done = True
+                        break
+                if len(items) < 2:
+                    break
+                if not self._bufs:
+                    self._make_buffers(items[0][0], items[0][1])
+                slot = self._free.get()
+                if slot is None:
+                    break
+                ib, db = self._bufs[slot]
+                for k, (img, dep) in enumerate(items):
+                    if img.shape != ib.shape[1:] or dep.shape != db.shape[1:]:
+                        raise ValueError("frame {} of the window has shape {} / {}, expected {} / {}".format(
+                            k, img.shape, dep.shape, ib.shape[1:], db.shape[1:]))
+                    ib[k] = img
+                    db[k] = dep
+                carry = (ib[len(items) - 1].copy(), db[len(items) - 1].copy())       # the next window may land in another slot
+                self.decode_seconds += time.perf_counter() - t0
+                self._q.put((slot, len(items)))
+        except BaseException as e:                  # surfaced in the consumer thread
+            self._err = e
+        finally:
+            self._q.put(None)
+
+    def __iter__(self) -> Iterator[Tuple[np.ndarray, np.ndarray, int]]:
+        if self._started:
+            raise RuntimeError("FrameWindows can be iterated once")
+        self._started = True
+        self._thread.start()
+        held: List[int] = []
+        try:
+            while True:
+                item = self._q.get()
+                if item is None:
+                    if self._err is not None:
+                        raise self._err
+                    return
+                slot, n = item
+                held.append(slot)
+                while len(held) > self._ring - 1:          # slots handed out longer ago than ring - 1 windows are free again
+                    self._free.put(held.pop(0))
+                ib, db = self._bufs[slot]
+                yield ib[:n], db[:n], n
+        finally:
+            self._stop = True
+            self._free.put(None)
+
+
+def align_windows(aligner, windows: Iterable[Tuple[np.ndarray, np.ndarray, int]], colour: bool, max_distance: float = 5.0):
+    """Feeds the windows through `aligner` (BatchAligner / StreamedAligner): the upload + solve of window k+1 is enqueued
+    before the poses of window k are fetched, so the copy engine, the GPU and the decoder thread all stay busy.
+    -> dict(T (n_pairs,3,4), iters, err, seconds)"""
+    T, iters, errs = [], [], []
+    t0 = time.perf_counter()
+    for img, dep, n in windows:
+        if colour:
+            res = aligner.align_host_bgr(img, dep, max_distance) if hasattr(aligner, "align_host_bgr") else _align_bgr(aligner, img, dep, max_distance)
+        else:
+            res = aligner.align_host(img, dep)
+        T.append(res["T"])
+        iters.append(res["iters"])
+        errs.append(res["err"])
+    return {"T": np.concatenate(T) if T else np.zeros((0, 3, 4), np.float32),
+            "iters": np.concatenate(iters) if iters else np.zeros(0, np.int32),
+            "err": np.concatenate(errs) if errs else np.zeros(0), "seconds": time.perf_counter() - t0}
+
+
+def _align_bgr(aligner, bgr, depth, max_distance):
+    aligner.ingest_host_bgr(bgr, depth, max_distance)
+    aligner.solve_enqueue(bgr.shape[0])
+    return aligner.solve_fetch(bgr.shape[0])
+
+
+# -- report files -------------------------------------------------------------------------------------------------
+def _se3_log6(T: np.ndarray) -> List[float]:
+    return [float(v) for v in Se3.from_matrix(np.asarray(T, dtype=np.float32)).log().reshape(6)]
+
+
+def build_report(kind: str, T_rel: np.ndarray, init_pose: Optional[np.ndarray], gt_T_wc: Optional[np.ndarray],
+                 timestamps, extra: Optional[dict] = None):
+    """-> (report dict, trajectory (n,4,4)).  Keys of the reference's report.json (src/test_dvo.py:323-329):
+    "estimated_poses" / "estimated_transforms" = 6-vector logs per frame (the first transform is the identity, :63-65),
+    "errors" = Euclidean distance of the estimated to the ground-truth position per frame ("N/A" without ground truth,
+    :314-319), plus "type" / "timestamps" as the loaders' additional info; added: the 4x4 forms and ATE / RPE."""
+    from . import tum
+    T_rel = np.asarray(T_rel, dtype=np.float64)
+    traj = compose_trajectory(T_rel, init_pose=(np.eye(4) if init_pose is None else init_pose))
+    n = traj.shape[0]
+    tf4 = np.tile(np.eye(4), (n, 1, 1))
+    tf4[1:, :3, :] = T_rel.reshape(-1, 3, 4)
+    report = {"type": kind,
+              "estimated_poses": [_se3_log6(P) for P in traj],
+              "estimated_transforms": [_se3_log6(P) for P in tf4],
+              "errors": (["N/A"] * n if gt_T_wc is None else
+                         [float(np.linalg.norm(traj[i, :3, 3] - np.asarray(gt_T_wc)[i, :3, 3])) for i in range(n)]),
+              "timestamps": [float(t) for t in np.asarray(timestamps)[:n]],
+              "estimated_poses_matrix": traj.reshape(n, 16).tolist(),
+              "estimated_transforms_matrix": tf4.reshape(n, 16).tolist()}
+    if gt_T_wc is not None:
+        report.update(tum.evaluate(traj, np.asarray(gt_T_wc)[:n]))
+    if extra:
+        report.update(extra)
+    return report, traj
+
+
+def write_report(out_dir: Path, report: dict, traj: np.ndarray) -> None:
+    """report.json + report.txt (TUM trajectory format `timestamp tx ty tz qx qy qz qw`, src/test_dvo.py:337-345; the
+    reference writes it for TUM data only, here always)."""
+    from . import tum
+    out_dir = Path(out_dir)
+    out_dir.mkdir(parents=True, exist_ok=True)
+    with (out_dir / "report.json").open("w") as fp:
+        json.dump(report, fp, indent=1)
+    tum.write_tum_trajectory(out_dir / "report.txt", report["timestamps"], traj)

@@ -137,6 +137,15 @@ int dvo_host_free(void* p);
  * depth*depth_scale > max_distance -> 0, on device (core/base_dense_visual_odometry.py:58-59). */
 int dvo_upload_frame_bgr(dvo_ctx* ctx, int slot, const uint8_t* bgr, const uint16_t* depth, int w, int h, int levels,
                          double max_distance);
+/* Batched colour ingest: n_frames contiguous [n][h][w][3] BGR images + [n][h][w] depth images into the listed (distinct)
+ * slots.  The host form moves the batch with two large copies like dvo_upload_frames (asynchronous for page-locked memory,
+ * on the shared copy stream when an upload peer is set), then one device pass converts / clamps all frames into the level-0
+ * planes and the batched pyramid build follows.  Replaces cvtColor + clamp of core/base_dense_visual_odometry.py:58-59 and
+ * the all-in-RAM frame loop of src/test_dvo.py:180-191 for colour sequences. */
+int dvo_upload_frames_bgr(dvo_ctx* ctx, int n_frames, const int* slots, const uint8_t* bgr, const uint16_t* depth,
+                          int w, int h, int levels, double max_distance);
+int dvo_upload_frames_bgr_device(dvo_ctx* ctx, int n_frames, const int* slots, const void* d_bgr, const void* d_depth,
+                                 int w, int h, int levels, double max_distance);
 /* Copies one level of a slot back to the host (any pointer may be NULL). gx/gy are the unpacked Sobel planes. */
 int dvo_download_level(dvo_ctx* ctx, int slot, int level, uint8_t* gray, uint16_t* depth, int16_t* gx, int16_t* gy);
 int dvo_slot_info(const dvo_ctx* ctx, int slot, int* w, int* h, int* levels);

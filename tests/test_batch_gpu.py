@@ -327,3 +327,88 @@ def test_student_t_reference_irls_needs_more_than_two_passes_on_a_tiny_level():
     _, _, err, n = dvo.compute_normal_equations(dvo_amd.Se3.identity(), level=0)       # host path: the reference's loop in Python
     assert n == 5 and abs(err - rec[0].err) <= 1e-5 * rec[0].err
     assert est is not None
+
+
+def test_batched_colour_ingest_bit_exact(frames):
+    """dvo_upload_frames_bgr: n colour frames in one batched upload; BGR->gray and the depth clamp of
+    core/base_dense_visual_odometry.py:58-59 on the device == oracle (bgr2gray + float64 clamp) == the per-frame
+    dvo_upload_frame_bgr path, bit for bit, pyramids and valid-point lists included."""
+    import dvo_amd
+    rng = np.random.default_rng(4)
+    bgr0 = frames["color_bgr_1"]
+    n = 3
+    bgr = np.stack([bgr0, np.roll(bgr0, 7, axis=1), rng.integers(0, 256, size=bgr0.shape, dtype=np.uint8)])
+    depth = np.stack([frames["depth"][k].copy() for k in range(n)])
+    scale, maxd = frames["depth_scale"], 5.0
+    # every depth value around the clamp threshold appears (the device compares integers; the reference a float64 product)
+    thr = int(maxd / scale)
+    depth[0, 10, :41] = np.arange(thr - 20, thr + 21, dtype=np.uint16)
+    depth[1, 100:120, 200:260] = 40000
+    K = frames["K"]
+    with dvo_amd.HipContext(max_w=640, max_h=480, max_levels=3, n_slots=4, max_pairs=2) as ctx:
+        ctx.set_camera(K[0, 0], K[1, 1], K[0, 2], K[1, 2], K[0, 1], scale)
+        ctx.upload_frames_bgr([0, 1, 2], bgr, depth, 3, maxd)
+        ctx.upload_frame_bgr(3, bgr[1], depth[1], 3, maxd)
+        ctx.synchronize()
+        for k in range(n):
+            gray = O.bgr2gray(bgr[k])
+            dk = depth[k].copy()
+            dk[(dk * scale) > maxd] = 0                                   # the reference's expression (float64 product)
+            gp, dp = O.build_pyramid(gray, 3), O.build_pyramid(dk, 3)
+            for lvl in range(3):
+                got = ctx.download_level(k, lvl)
+                assert np.array_equal(got["gray"], gp[lvl]) and np.array_equal(got["depth"], dp[lvl]), (k, lvl)
+                gx, gy = O.sobel3(gp[lvl])
+                assert np.array_equal(got["gx"], gx.astype(np.int16)) and np.array_equal(got["gy"], gy.astype(np.int16))
+                pts = ctx.download_points(k, lvl)
+                ys, xs = np.nonzero(dp[lvl])
+                assert np.array_equal(pts["x"], xs) and np.array_equal(pts["y"], ys)
+        a, b = ctx.download_level(1, 0), ctx.download_level(3, 0)
+        assert np.array_equal(a["gray"], b["gray"]) and np.array_equal(a["depth"], b["depth"])
+        assert (depth[0, 10, :41] != 0).all() and (ctx.download_level(0, 0, want=("depth",))["depth"][10, :41] == 0).sum() in (19, 20, 21)
+
+
+def test_streamed_colour_alignment_equals_gray_alignment(vga_stream):
+    """StreamedAligner.align_host_bgr (colour frames, page-locked, conversion on the device) gives the poses of the gray
+    path on the gray-equivalent input (B = G = R), bit for bit."""
+    from dvo_amd.batch import StreamedAligner
+    from dvo_amd import _cabi
+    st = vga_stream
+    n = 9
+    bgr = _cabi.pinned_array((n, 480, 640, 3), np.uint8)
+    dep = _cabi.pinned_array((n, 480, 640), np.uint16)
+    bgr[...] = st["gray"][:n, :, :, None]
+    dep[...] = st["depth"][:n]
+    al = StreamedAligner(st["K"], st["depth_scale"], 640, 480, 4, max_pairs=8, n_streams=2, max_iterations=6)
+    a = al.align_host_bgr(bgr, dep, max_distance=1e9)
+    b = al.align_host(st["gray"][:n], st["depth"][:n])
+    al.close()
+    assert np.array_equal(a["xi"], b["xi"]) and np.array_equal(a["iters"], b["iters"])
+
+
+@pytest.mark.parametrize("colour", [False, True])
+def test_run_sequence_fixture_end_to_end(tmp_path, golden_dir, colour):
+    """tools/run_sequence.py --fixture: decoder thread -> page-locked windows -> batched (gray or colour) upload -> device
+    solve -> report.json in the reference's shape + TUM trajectory; ATE equal to the reference run's on the same excerpt."""
+    import json
+    import subprocess
+    import sys
+    from pathlib import Path
+    from dvo_amd import tum
+    from dvo_amd.batch import absolute_trajectory_error
+    root = Path(__file__).resolve().parents[1]
+    cmd = [sys.executable, str(root / "tools" / "run_sequence.py"), "--fixture", "--out", str(tmp_path), "--window", "4"]
+    out = subprocess.run(cmd + (["--colour"] if colour else []), capture_output=True, text=True, timeout=600, cwd=str(root))
+    assert out.returncode == 0, out.stderr[-3000:]
+    line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    g = np.load(golden_dir / "sequence.npz")
+    f = np.load(golden_dir / "frames.npz")
+    ref_ate = absolute_trajectory_error(g["pose_T"].astype(np.float64), f["gt_T"])
+    assert abs(line["ate_rmse_m"] - ref_ate) < 1e-6 and abs(ref_ate - 4.1317e-3) < 1e-6
+    assert line["frames"] == 10 and line["input"] == ("bgr" if colour else "gray") and line["type"] == "TEST"
+    rep = json.loads((tmp_path / "report.json").read_text())
+    np.testing.assert_allclose(np.array(rep["estimated_transforms"]), g["tf_xi"].reshape(10, 6), atol=3e-6)
+    np.testing.assert_allclose(np.array(rep["estimated_poses"]), g["pose_xi"].reshape(10, 6), atol=3e-5)
+    stamps, T = tum.read_tum_trajectory(tmp_path / "report.txt")
+    np.testing.assert_allclose(T, np.array(rep["estimated_poses_matrix"]).reshape(10, 4, 4), atol=1e-5)
+    assert len(stamps) == 10

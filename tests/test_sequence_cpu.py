@@ -1,0 +1,72 @@
+"""Sequence front end (dvo_amd/sequence.py), CPU part: windows of frames decoded by a background thread, and the report
+files in the reference's shape (src/test_dvo.py:323-345)."""
+import json
+
+import numpy as np
+import pytest
+
+from dvo_amd import sequence, tum
+
+
+def _frames(n, h=6, w=8, colour=False):
+    for k in range(n):
+        img = np.full((h, w, 3) if colour else (h, w), k, dtype=np.uint8)
+        yield img, np.full((h, w), 1000 + k, dtype=np.uint16)
+
+
+@pytest.mark.parametrize("n,window", [(10, 4), (9, 4), (2, 4), (5, 1), (13, 12)])
+def test_frame_windows_cover_every_pair_once(n, window):
+    seen = []
+    for img, dep, m in sequence.FrameWindows(_frames(n), window):
+        assert img.shape[0] == dep.shape[0] == m and 2 <= m <= window + 1
+        ids = [int(img[k, 0, 0]) for k in range(m)]
+        assert ids == [int(dep[k, 0, 0]) - 1000 for k in range(m)]
+        assert ids == list(range(ids[0], ids[0] + m))
+        seen += [(a, a + 1) for a in ids[:-1]]
+    assert seen == [(a, a + 1) for a in range(n - 1)]          # consecutive windows share exactly one frame
+
+
+def test_frame_windows_colour_and_errors():
+    wins = list(sequence.FrameWindows(_frames(5, colour=True), 2))
+    assert wins[0][0].shape == (3, 6, 8, 3) and len(wins) == 2
+    assert list(sequence.FrameWindows(_frames(1), 4)) == []    # one frame: no pair
+
+    def bad():
+        yield np.zeros((6, 8), np.uint8), np.zeros((6, 8), np.uint16)
+        yield np.zeros((6, 9), np.uint8), np.zeros((6, 9), np.uint16)
+
+    with pytest.raises(ValueError):
+        list(sequence.FrameWindows(bad(), 4))
+
+    def broken():
+        yield np.zeros((6, 8), np.uint8), np.zeros((6, 8), np.uint16)
+        raise OSError("unreadable png")
+
+    with pytest.raises(OSError):                               # decoder errors surface in the consumer
+        list(sequence.FrameWindows(broken(), 4))
+
+
+def test_report_has_the_references_shape(tmp_path, golden_dir):
+    """report.json keys / shapes of src/test_dvo.py:323-329 and the TUM txt of :337-345, from the chained reference run's own
+    transforms: the 6-vector logs must reproduce the reference's recorded poses."""
+    g = np.load(golden_dir / "sequence.npz")
+    f = np.load(golden_dir / "frames.npz")
+    T_rel = g["tf_T"][1:, :3, :]
+    report, traj = sequence.build_report("TEST", T_rel, g["pose_T"][0].astype(np.float64), f["gt_T"], np.arange(10.0),
+                                         {"input": "gray"})
+    n = 10
+    assert len(report["estimated_poses"]) == len(report["estimated_transforms"]) == len(report["errors"]) == n
+    assert all(len(p) == 6 for p in report["estimated_poses"]) and report["estimated_transforms"][0] == [0.0] * 6
+    np.testing.assert_allclose(np.array(report["estimated_poses"]), g["pose_xi"].reshape(n, 6), atol=2e-5)
+    np.testing.assert_allclose(np.array(report["estimated_transforms"]), g["tf_xi"].reshape(n, 6), atol=2e-6)
+    np.testing.assert_allclose(traj, g["pose_T"], atol=5e-6)
+    assert report["errors"][0] < 1e-6 and all(isinstance(e, float) for e in report["errors"])
+    assert 0.003 < report["ate_rmse_m"] < 0.006 and report["type"] == "TEST" and report["input"] == "gray"
+    sequence.write_report(tmp_path, report, traj)
+    back = json.loads((tmp_path / "report.json").read_text())
+    assert back["estimated_poses"] == report["estimated_poses"]
+    stamps, T = tum.read_tum_trajectory(tmp_path / "report.txt")
+    np.testing.assert_allclose(stamps, np.arange(10.0))
+    np.testing.assert_allclose(T, traj, atol=1e-5)          # (the float32 ground-truth start pose is orthonormal to ~3e-6 only)
+    r2, _ = sequence.build_report("X", T_rel, None, None, np.arange(10.0))
+    assert r2["errors"] == ["N/A"] * n and "ate_rmse_m" not in r2
