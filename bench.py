@@ -62,45 +62,75 @@ def parse_args():
     ap.add_argument("--spawn", action="store_true",
                     help="start the ranks through the launcher even for --gpus 1 (rehearses the multi-GPU entry on one GPU)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-pairs", type=int, default=32, help="frame pairs of the CPU baseline sample (~0.35 s each)")
+    ap.add_argument("--cpu-pairs", type=int, default=16, help="frame pairs of the CPU baseline sample (~0.35 s each on one thread)")
     return ap.parse_args()
 
 
+def _median_iteration_ms(O, g0, d0, g1, K, depth_scale, n_iter):
+    """One level-0 Gauss-Newton iteration of the oracle = the reference's call graph per iteration (deproject -> J_w -> transform ->
+    project -> 3x bilinear -> J -> float32 J^T J -> 6x6 solve): median of n_iter runs after one warm-up."""
+    import numpy as np
+    lv = O.PairLevel(g0, d0, g1, O.level_intrinsics(K, 0), depth_scale)
+    T = O.Pose.from_xi(np.array([0.002, -0.001, 0.003, 0.001, -0.002, 0.0015])).matrix()
+    ts = []
+    for k in range(n_iter + 1):
+        t0 = time.perf_counter()
+        r, J, _, _ = O.residuals_and_jacobian(lv, T)
+        H, b, _, _ = O.normal_equations(r, J, None, "fp32")
+        O.solve_increment(H, b)
+        if k:
+            ts.append(time.perf_counter() - t0)
+    return 1e3 * float(np.median(ts))
+
+
 def cpu_baseline(stream_np, levels, iterations, n_pairs):
-    """Oracle (NumPy port of the reference CPU path, float32 J^T J like the reference) on a bounded sample."""
+    """the NumPy oracle (a port of the reference's CPU path, float32 J^T J like the reference) on this host, on a
+    bounded sample of the bench workload: per level-0 GN iteration (median of 20) and per full frame pair, with one thread and
+    with every core NumPy's BLAS / a worker pool may use, plus a 1280x960 leg.  The real reference adds numba-parallel loops
+    and ~25 ms of np_cache key hashing per iteration (utils/numpy_cache.py:33-43): this is a favourable stand-in for it."""
     import numpy as np
     sys.path.insert(0, str(ROOT / "oracle"))
     import dvo_oracle as O
-    try:
-        from threadpoolctl import threadpool_limits
-        limiter = threadpool_limits(limits=1)
-    except Exception:          # pragma: no cover
-        limiter = None
+    from threadpoolctl import threadpool_limits, threadpool_info
     g, d = stream_np["gray"], stream_np["depth"]
+    K, sc = stream_np["K"], stream_np["depth_scale"]
     n_pairs = min(n_pairs, g.shape[0] - 1)
-    O.gauss_newton(g[0], d[0], g[1], stream_np["K"], stream_np["depth_scale"], levels=levels,
-                   max_iterations=1, accumulate="fp32")                      # warm-up
-    t0 = time.perf_counter()
-    for k in range(n_pairs):
-        O.gauss_newton(g[k], d[k], g[k + 1], stream_np["K"], stream_np["depth_scale"], levels=levels,
-                       max_iterations=iterations, accumulate="fp32")
-    dt = time.perf_counter() - t0
-    if limiter is not None:
-        limiter.unregister() if hasattr(limiter, "unregister") else None
+    host_cpus = os.cpu_count() or 1
+    try:
+        usable = len(os.sched_getaffinity(0))
+    except Exception:                                             # pragma: no cover
+        usable = host_cpus
+    # --- one thread ---------------------------------------------------------------------------------------------------
+    with threadpool_limits(limits=1):
+        it_ms_1 = _median_iteration_ms(O, g[0], d[0], g[1], K, sc, 20)
+        O.gauss_newton(g[0], d[0], g[1], K, sc, levels=levels, max_iterations=1, accumulate="fp32")     # warm-up
+        t0 = time.perf_counter()
+        for k in range(n_pairs):
+            O.gauss_newton(g[k], d[k], g[k + 1], K, sc, levels=levels, max_iterations=iterations, accumulate="fp32")
+        dt = time.perf_counter() - t0
     out = {"value": n_pairs / dt, "unit": "frame-pairs/s", "cores": 1, "kind": "port",
-           "sample": "%d VGA frame pairs x %d levels x %d GN iterations, NumPy oracle (float32 J^T J), 1 thread, "
-                     "%.1f s; host has %d logical CPUs" % (n_pairs, levels, iterations, dt, os.cpu_count() or 0)}
-    # the same sample spread over worker processes (pairs are independent, as on the GPU): the host's throughput with the
-    # cores one GPU's share of the node has.  The workers are plain child processes running oracle/cpu_worker.py: they
-    # import NumPy and the oracle only, never torch / HIP.  Each reports the seconds of its own range (interpreter
-    # start-up and a warm-up pair excluded); they start together, so the slowest worker's time is the wall time.
+           "sample": "%d VGA frame pairs x %d levels x %d GN iterations, NumPy oracle (float32 J^T J), 1 thread, %.1f s; host has %d "
+                     "logical CPUs (%d usable by this process)" % (n_pairs, levels, iterations, dt, host_cpus, usable),
+           "per_iteration_ms_vga_level0": {"threads_1": it_ms_1, "iterations_timed": 20},
+           "host_logical_cpus": host_cpus, "usable_cpus": usable}
+    # --- every BLAS thread the process may use (the only parallelism inside one NumPy iteration is the J^T J sgemm) ------
+    try:
+        blas_threads = max([i.get("num_threads", 1) for i in threadpool_info()] or [1])
+        out["per_iteration_ms_vga_level0"]["threads_all"] = _median_iteration_ms(O, g[0], d[0], g[1], K, sc, 20)
+        out["per_iteration_ms_vga_level0"]["blas_threads"] = blas_threads
+    except Exception as e:                                        # pragma: no cover
+        out["per_iteration_ms_vga_level0"]["threads_all_error"] = repr(e)
+    # --- every core: independent pairs over worker processes (pairs are independent, as on the GPU).  The pool is capped at 16
+    # workers: one GPU's share of the node's cores on this pool (gpurun's own guidance for a 1-GPU box), and what the memory cap
+    # and process guard of a box allow safely.  Plain child processes running oracle/cpu_worker.py: NumPy + oracle only, never
+    # torch / HIP.  Each reports the seconds of its own range (start-up and a warm-up pair excluded); they start together.
     try:
         import subprocess
         import tempfile
-        workers = max(1, min(16, os.cpu_count() or 1, n_pairs))
+        workers = max(1, min(16, usable, n_pairs))
         with tempfile.TemporaryDirectory() as tmp:
             path = os.path.join(tmp, "cpu_sample.npz")
-            np.savez(path, gray=g[:n_pairs + 1], depth=d[:n_pairs + 1], K=stream_np["K"], depth_scale=stream_np["depth_scale"])
+            np.savez(path, gray=g[:n_pairs + 1], depth=d[:n_pairs + 1], K=K, depth_scale=sc)
             bounds = [round(i * n_pairs / workers) for i in range(workers + 1)]
             env = dict(os.environ, OMP_NUM_THREADS="1", OPENBLAS_NUM_THREADS="1", MKL_NUM_THREADS="1")
             procs = [subprocess.Popen([sys.executable, str(ROOT / "oracle" / "cpu_worker.py"), path, str(bounds[i]), str(bounds[i + 1]),
@@ -111,6 +141,21 @@ def cpu_baseline(stream_np, levels, iterations, n_pairs):
                               "sample": "the same %d pairs over %d single-threaded worker processes, slowest worker %.1f s" % (n_pairs, workers, dtp)}
     except Exception as e:                                            # pragma: no cover
         out["all_workers"] = {"error": repr(e)}
+    # --- 1280x960, 5 levels (BASELINE config 3 shape): the VGA frames upsampled 2x (same texture statistics), one thread ------
+    try:
+        big = [np.repeat(np.repeat(a, 2, axis=0), 2, axis=1) for a in (g[0], d[0], g[1])]
+        Kb = np.array(K, dtype=np.float32).copy()
+        Kb[:2, :] *= 2.0
+        with threadpool_limits(limits=1):
+            it_big = _median_iteration_ms(O, big[0], big[1], big[2], Kb, sc, 5)
+            t0 = time.perf_counter()
+            O.gauss_newton(big[0], big[1], big[2], Kb, sc, levels=5, max_iterations=iterations, accumulate="fp32")
+            dtb = time.perf_counter() - t0
+        out["w1280x960"] = {"per_iteration_ms_level0_threads_1": it_big, "iterations_timed": 5,
+                            "frame_pairs_per_s_threads_1": 1.0 / dtb,
+                            "sample": "one 1280x960 pair (VGA frames upsampled 2x), 5 levels x %d iterations, 1 thread, %.1f s" % (iterations, dtb)}
+    except Exception as e:                                            # pragma: no cover
+        out["w1280x960"] = {"error": repr(e)}
     return out
 
 
@@ -164,14 +209,11 @@ def main():
     torch.cuda.set_device(local_rank)
     # under a launcher the process group is always formed (also for one rank: the same RCCL code path as N ranks)
     use_dist = launch.started_by_launcher() or os.environ.get("DVO_BENCH_FORCE_DIST") == "1"
-    if use_dist:
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
-        world = dist.get_world_size()                      # the ranks that actually joined
-        if world != args.gpus:
-            raise SystemExit("bench.py: %d ranks joined the process group, --gpus %d" % (world, args.gpus))
+    # (the process group is formed further down, AFTER this rank's device buffers and streams exist: creating the RCCL
+    # communicator first costs the whole step ~4 % on MI355X — measured, profiles/r02_experiments.txt)
 
     from dvo_amd import synthetic
-    from dvo_amd.batch import StreamedAligner, pose_records, allgather_poses
+    from dvo_amd.batch import StreamedAligner, pose_records, PoseGatherer
 
     B, W, H, L = args.batch, args.width, args.height, args.levels
     n_frames = B + 1
@@ -190,12 +232,22 @@ def main():
                          max_iterations=args.iterations, weighting=args.weighting,
                          approximate_image2_gradient=(args.variant == "v2"),
                          reference_variant="cuda" if args.variant == "v3" else "cpu")
-    counts = [B] * world
+    if use_dist:
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        world = dist.get_world_size()                      # the ranks that actually joined
+        if world != args.gpus:
+            raise SystemExit("bench.py: %d ranks joined the process group, --gpus %d" % (world, args.gpus))
+    gather = PoseGatherer([B] * world, device="cuda") if use_dist else None
+
+    gather_s = [0.0]
 
     def step():
         res = al.align_device(gray.data_ptr(), depth.data_ptr(), n_frames)
         if use_dist:
-            allgather_poses(pose_records(res["T"], res["iters"], res["err"]), counts, device="cuda")
+            tg = time.perf_counter()
+            allrec = gather(pose_records(res["T"], res["iters"], res["err"]))       # every rank ends the step with all poses
+            gather_s[0] += time.perf_counter() - tg
+            assert allrec.shape[0] == B * world
         return res
 
     for _ in range(args.warmup):
@@ -210,6 +262,7 @@ def main():
             dist.barrier()
 
     fence()
+    gather_s[0] = 0.0
     t0 = time.perf_counter()
     for _ in range(args.steps):
         res = step()
@@ -263,6 +316,7 @@ def main():
                        "batch_pairs_per_gpu": B, "streams_per_gpu": args.streams, "distinct_frames": int(min(n_distinct, n_frames)),
                        "gn_iterations_per_pair": iters_total / B,
                        "gn_iterations_per_s": world * iters_total * args.steps / elapsed,
+                       "pose_gather_ms_per_step": (1e3 * gather_s[0] / args.steps) if use_dist else None,
                        "parallelism": "1 independent stream per GPU, RCCL all-gather of pose records"},
             "roofline": {"bound": "hbm", "limiter_measured": "VALU issue, with the HBM stream (`traffic` / launch time) at 55-66 % of peak (DESIGN.md section 5)", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS,

@@ -56,7 +56,7 @@ import os, sys
 import numpy as np
 import torch.distributed as dist
 sys.path.insert(0, os.environ["DVO_PKG_DIR"])
-from dvo_amd.batch import shard_pairs, pose_records, allgather_poses, compose_trajectory
+from dvo_amd.batch import shard_pairs, pose_records, allgather_poses, compose_trajectory, PoseGatherer
 
 dist.init_process_group(backend="gloo")
 rank, world = dist.get_rank(), dist.get_world_size()
@@ -71,6 +71,9 @@ assert allrec.shape == (n, 16), allrec.shape
 assert np.array_equal(allrec[:, :12].reshape(n, 3, 4), T_all.astype(np.float32))
 assert np.array_equal(allrec[:, 12], np.arange(n, dtype=np.float32))            # order preserved across ranks
 assert np.array_equal(allrec[:, 13], np.repeat(np.arange(world, dtype=np.float32), counts))
+gather = PoseGatherer(counts)                      # the step-loop form: persistent buffers, same result, call after call
+for _ in range(3):
+    assert np.array_equal(gather(local), allrec)
 poses = compose_trajectory(allrec, init_pose=g["pose_T"][0].astype(np.float64))
 assert np.abs(poses - g["pose_T"]).max() < 5e-6
 dist.barrier()
