@@ -32,11 +32,12 @@ class FrameWindows:
     iteration is (image_window, depth_window, n_frames_in_window): views into a ring slot that stay valid until `depth`
     further windows have been requested (`ring` = 3 by default: one being aligned, one uploaded, one being filled)."""
 
-    def __init__(self, frames: Iterable[Tuple[np.ndarray, np.ndarray]], window_pairs: int,
-                 alloc: Callable = None, ring: int = 3):
+    def __init__(self, frames: Iterable, window_pairs: int, alloc: Callable = None, ring: int = 3, workers: int = 0):
+        """`frames` may also yield zero-argument callables returning (image, depth) — e.g. PNG decoders; with `workers` > 0
+        they run in a pool of that many threads (PIL releases the GIL while decoding), results kept in sequence order."""
         if window_pairs < 1 or ring < 2:
             raise ValueError("window_pairs >= 1 and ring >= 2 required")
-        self._frames = iter(frames)
+        self._frames = self._resolve(iter(frames), workers)
         self._w = window_pairs
         self._alloc = alloc or (lambda shape, dtype: np.empty(shape, dtype=dtype))
         self._ring = ring
@@ -48,6 +49,25 @@ class FrameWindows:
         self._started = False
         self._stop = False
         self.decode_seconds = 0.0
+
+    @staticmethod
+    def _resolve(it, workers):
+        if workers <= 0:
+            for item in it:
+                yield item() if callable(item) else item
+            return
+        from collections import deque
+        from concurrent.futures import ThreadPoolExecutor
+        with ThreadPoolExecutor(max_workers=workers, thread_name_prefix="dvo-png") as pool:
+            pending = deque()
+            for item in it:
+                pending.append(pool.submit(item) if callable(item) else item)
+                if len(pending) >= 2 * workers:
+                    head = pending.popleft()
+                    yield head.result() if hasattr(head, "result") else head
+            while pending:
+                head = pending.popleft()
+                yield head.result() if hasattr(head, "result") else head
 
     def _make_buffers(self, img, depth):
         shape = (self._w + 1,) + tuple(img.shape)
@@ -116,8 +136,8 @@ class FrameWindows:
 
 
 def align_windows(aligner, windows: Iterable[Tuple[np.ndarray, np.ndarray, int]], colour: bool, max_distance: float = 5.0):
-    """Feeds the windows through `aligner` (BatchAligner / StreamedAligner): the upload + solve of window k+1 is enqueued
-    before the poses of window k are fetched, so the copy engine, the GPU and the decoder thread all stay busy.
+    """Feeds the windows through `aligner` (BatchAligner / StreamedAligner).  While window k is uploaded and solved the decoder
+    thread fills window k+1; inside a window the slices of a StreamedAligner overlap one slice's upload with another's solve.
     -> dict(T (n_pairs,3,4), iters, err, seconds)"""
     T, iters, errs = [], [], []
     t0 = time.perf_counter()

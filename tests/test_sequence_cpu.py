@@ -26,6 +26,22 @@ def test_frame_windows_cover_every_pair_once(n, window):
     assert seen == [(a, a + 1) for a in range(n - 1)]          # consecutive windows share exactly one frame
 
 
+def test_frame_windows_with_a_decoder_pool_keeps_the_order():
+    import time
+
+    def thunks(n):
+        for k in range(n):
+            def load(k=k):
+                time.sleep(0.002 * ((k * 7) % 5))              # decoders finish out of order
+                return np.full((6, 8), k, dtype=np.uint8), np.full((6, 8), 1000 + k, dtype=np.uint16)
+            yield load
+
+    ids = []
+    for img, dep, m in sequence.FrameWindows(thunks(23), 5, workers=4):
+        ids += [int(img[k, 0, 0]) for k in range(m if not ids else m)][(1 if ids else 0):]
+    assert ids == list(range(23))
+
+
 def test_frame_windows_colour_and_errors():
     wins = list(sequence.FrameWindows(_frames(5, colour=True), 2))
     assert wins[0][0].shape == (3, 6, 8, 3) and len(wins) == 2

@@ -38,6 +38,7 @@ def parse_args():
     ap.add_argument("--weighting", default="none", choices=["none", "student_t_reference", "student_t", "huber"])
     ap.add_argument("--window", type=int, default=128, help="frame pairs per batched upload + solve")
     ap.add_argument("--streams", type=int, default=2, help="HIP streams (slices of a window) per GPU")
+    ap.add_argument("--decoders", type=int, default=8, help="PNG decoder threads (TUM mode)")
     ap.add_argument("--colour", action="store_true", help="feed BGR frames (conversion + depth clamp on the device) "
                                                            "also for --fixture / --synthetic (B = G = R)")
     ap.add_argument("--camera", type=Path, default=None, help="camera_intrinsics.yaml (TUM mode; default fr1)")
@@ -69,12 +70,11 @@ def main():
         except launch.LaunchError as e:
             raise SystemExit("run_sequence.py: %s" % e)
         import torch
-        import torch.distributed as dist
         if local_rank >= torch.cuda.device_count():
             raise SystemExit("run_sequence.py: rank %d has no GPU" % rank)
         torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
-        world = dist.get_world_size()
+        # (the process group is formed after this rank's alignment: creating the RCCL communicator before the device buffers
+        # and streams exist slows the kernels by ~4 %, profiles/r02_experiments.txt; rank and world size come from the launcher)
 
     # -- the sequence: (n_total, frame source for a range, ground truth, intrinsics, stamps) ------------------------
     colour = args.colour
@@ -103,9 +103,9 @@ def main():
         scale = cam.depth_scale if cam else synthetic.DEPTH_SCALE
         gt, stamps, kind, colour, n_total = seq.gt_T_wc, seq.timestamps, "TUM", True, len(seq)
 
-        def source(lo, hi):                          # decoded lazily, by the prefetch thread, for this rank's range only
+        def source(lo, hi):                          # decoded lazily, by the decoder pool, for this rank's range only
             for k in range(lo, hi):
-                yield tum.read_frame(seq.rgb_paths[k], seq.depth_paths[k])
+                yield (lambda k=k: tum.read_frame(seq.rgb_paths[k], seq.depth_paths[k]))
 
     lo, hi = shard_pairs(n_total - 1, rank, world) if use_dist else (0, n_total - 1)
     n_local = hi - lo                                # pairs lo..hi-1 need frames lo..hi (one duplicated boundary frame per rank)
@@ -113,18 +113,23 @@ def main():
     decode_s = 0.0
     if n_local > 0:
         first = next(iter(source(lo, lo + 1)))
+        first = first() if callable(first) else first
         h, w = first[1].shape
         window = max(args.streams, min(args.window, n_local))
         al = StreamedAligner(K, scale, w, h, args.levels, max_pairs=window, n_streams=args.streams, device=local_rank,
                              max_iterations=args.iterations, weighting=args.weighting)
-        windows = sequence.FrameWindows(source(lo, hi + 1), window, alloc=_cabi.pinned_array)
+        windows = sequence.FrameWindows(source(lo, hi + 1), window, alloc=_cabi.pinned_array, workers=args.decoders)
         res = sequence.align_windows(al, windows, colour)
         decode_s = windows.decode_seconds
         al.close()
     T_rel, iters = res["T"], res["iters"]
 
     if use_dist:
+        import torch
         import torch.distributed as dist
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if dist.get_world_size() != world:
+            raise SystemExit("run_sequence.py: %d ranks joined, %d expected" % (dist.get_world_size(), world))
         counts = [shard_pairs(n_total - 1, r, world)[1] - shard_pairs(n_total - 1, r, world)[0] for r in range(world)]
         rec = allgather_poses(pose_records(T_rel, iters), counts, device="cuda")
         T_rel, iters = rec[:, :12].reshape(-1, 3, 4), rec[:, 12]
