@@ -538,6 +538,15 @@ __global__ __launch_bounds__(DVO_BLOCK) void k_list_build(const DvoBatchIngestPa
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     DvoPointRec* list = reinterpret_cast<DvoPointRec*>(slot + g.off_list) + *segc;     // exclusive offset (k_list_scan)
     for (int i = lane; i < total; i += 64) list[i] = st[i];
+    if (sl == g.nseg - 1) {
+        // tail padding: 256 records with z = NaN behind the last real one (inside DVO_LIST_SLACK).  A wave of k_reduce reads whole
+        // 256-record groups; a NaN depth makes every warped coordinate NaN, which fails the in-bounds test like any other invalid
+        // point — so the reduction needs no per-record `index < count` test (2 instructions per point).
+        DvoPointRec pad;
+        pad.z = __builtin_nanf("");
+        pad.pix = 0u;
+        for (int i = lane; i < 64 * DVO_PX_PER_THREAD; i += 64) list[total + i] = pad;
+    }
 }
 
 // exclusive scan of the per-segment counts of one (frame, level); total -> list_count[slot][level]
@@ -1000,7 +1009,8 @@ __global__ __launch_bounds__(DVO_BLOCK, (VARIANT == 2) ? 2 : DVO_REDUCE_WAVES_PE
         float jv3[(VARIANT == 2) ? DVO_PX_PER_THREAD : 1][6];
 #pragma unroll
         for (int j = 0; j < DVO_PX_PER_THREAD; ++j) {
-            const bool live = (seg + j * 64 + lane_) < count;
+            // V1 / V2: records past `count` are the list's NaN padding (k_list_build) and fail the bounds test by themselves
+            const bool live = (VARIANT == 2) ? ((seg + j * 64 + lane_) < count) : true;
             const unsigned pix = rc[j].y;
             const unsigned xi = pix & 0xfffu, yi = (pix >> 12) & 0xfffu;
             if constexpr (VARIANT == 2) {
