@@ -1430,12 +1430,13 @@ __device__ inline void se3_log(const double* q, const double* t, double* xi)
 // Minimum-norm solution of a numerically rank-deficient symmetric 6x6 system through a cyclic Jacobi
 // eigen-decomposition (what LAPACK gelsy, base_robust_dvo.py:196-198, returns for a rank-deficient system).
 // Rare path: kept out of line so its runtime-indexed arrays do not push the common path into scratch.
-__device__ __noinline__ void solve6_pinv(const double* hu, const double* b, double dmax, double* x)
+__device__ __noinline__ void solve6_pinv(const double* hu, const double* b, double dmax, double* x, double* ws /* [72] LDS */)
 {
-    // every loop is kept rolled (#pragma unroll 1): A and V then stay runtime-indexed arrays in scratch and the function needs
-    // a dozen registers; unrolled, the compiler promotes both matrices to registers (128 VGPRs + spills), and a callee's
-    // registers count against every kernel that can reach it
-    double A[6][6], V[6][6];
+    // every loop is kept rolled (#pragma unroll 1) and the two matrices live in a workspace the caller provides in LDS (one lane
+    // per workgroup runs the control step): the function then needs a dozen registers and no scratch; unrolled, the compiler
+    // promotes both matrices to registers (128 VGPRs + spills), and a callee's registers count against every kernel that can reach it
+    double (*A)[6] = reinterpret_cast<double (*)[6]>(ws);
+    double (*V)[6] = reinterpret_cast<double (*)[6]>(ws + 36);
     {
         int q = 0;
 #pragma unroll 1
@@ -1501,7 +1502,7 @@ __device__ __noinline__ void solve6_pinv(const double* hu, const double* b, doub
 // lo6(i, j), i >= j: position of element (i, j) of the lower triangle = position of (j, i) in the row-major upper triangle.
 __device__ __forceinline__ constexpr int lo6(int i, int j) { return j * 6 - (j * (j - 1)) / 2 + (i - j); }
 
-__device__ __forceinline__ void solve6(const double* hu, const double* b, double* x)
+__device__ __forceinline__ void solve6(const double* hu, const double* b, double* x, double* ws /* [72] LDS, rare path */)
 {
     double a[21];
 #pragma unroll
@@ -1568,7 +1569,7 @@ __device__ __forceinline__ void solve6(const double* hu, const double* b, double
         }
         return;
     }
-    solve6_pinv(hu, b, dmax, x);
+    solve6_pinv(hu, b, dmax, x, ws);
 }
 
 __global__ void k_init_state(DvoPairState* st, float* T, const float* T_init, int n_pairs, double lambda0,
@@ -1657,7 +1658,7 @@ hipError_t dvo_launch_level_begin(DvoPairState* st, int* active, double* wparam,
 // state / T / active / wparam in global memory) or DvoSmallParams (k_gn_small: the same objects held in LDS).
 template <class P>
 __device__ __forceinline__ void gn_control(const P& p, int phase, int pair, DvoPairState& st, float* T, int* active,
-                                           double* wparam, double* rec)
+                                           double* wparam, double* rec, double* ws /* [72] LDS workspace */)
 {
     if (phase != 0) {
         // Student-t scale pass k (weighter/t_weighter.py:24-32): lambda <- 1 / scale, stop when lambda has settled.
@@ -1686,7 +1687,7 @@ __device__ __forceinline__ void gn_control(const P& p, int phase, int pair, DvoP
         for (int i = 0; i < 6; ++i) { rec[dg[i]] += p.inv_sigma; bneg[i] += p.inv_sigma * xo[i]; nrm += xo[i] * xo[i]; }
         err += 0.5 * (1.0 / p.inv_sigma) * sqrt(nrm);
     }
-    solve6(rec, bneg, inc);
+    solve6(rec, bneg, inc, ws);
     st.iters += 1;
     st.err_last = err;
     if (p.trace != nullptr && st.iters <= p.trace_cap) {
@@ -1775,7 +1776,7 @@ __global__ __launch_bounds__(64) void k_solve(const DvoSolveParams p)
         __syncthreads();
     }
     if (threadIdx.x != 0) return;
-    gn_control(p, p.phase, pair, p.state[pair], p.T + (size_t)pair * 12, p.active + pair, p.wparam + pair, rec);
+    gn_control(p, p.phase, pair, p.state[pair], p.T + (size_t)pair * 12, p.active + pair, p.wparam + pair, rec, &tmp[0][0]);
 }
 
 hipError_t dvo_launch_solve(const DvoSolveParams& p, hipStream_t s)
@@ -2002,7 +2003,7 @@ __global__ __launch_bounds__(DVO_SMALL_MAX_THREADS) void k_gn_small(const DvoSma
                 rec_sh[tid] = t;
             }
             __syncthreads();
-            if (tid == 0) gn_control(p, 0, pair, st, T_sh, &active_sh, &wpar_sh, rec_sh);
+            if (tid == 0) gn_control(p, 0, pair, st, T_sh, &active_sh, &wpar_sh, rec_sh, &wsum[0][0]);
             __syncthreads();
         }
         __syncthreads();

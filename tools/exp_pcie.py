@@ -33,3 +33,16 @@ for streams in (1, 2, 4):
     dt = (time.perf_counter() - t0) / 5
     print("pinned, %d stream(s): upload + full solve of %d pairs: %.2f ms -> %.0f frame-pairs/s (PCIe-inclusive)" % (streams, B, 1e3 * dt, B / dt))
     sa.close()
+
+# colour input (BGR u8: 3 B/px + depth 2 B/px over the link; conversion + clamp on the device)
+bgr = _cabi.pinned_array((B + 1, 480, 640, 3), np.uint8); bgr[...] = g[:, :, :, None]
+for streams in (2, 4):
+    sa = StreamedAligner(st["K"], st["depth_scale"], 640, 480, 4, max_pairs=B, n_streams=streams, max_iterations=10)
+    sa.align_host_bgr(bgr, dp)
+    t0 = time.perf_counter()
+    for _ in range(5):
+        res = sa.align_host_bgr(bgr, dp)
+    dt = (time.perf_counter() - t0) / 5
+    print("pinned BGR, %d stream(s): upload + colour conversion + full solve of %d pairs: %.2f ms -> %.0f frame-pairs/s (PCIe-inclusive, %.1f GB/s)" % (
+        streams, B, 1e3 * dt, B / dt, (B + 1) * 640 * 480 * 5 / dt / 1e9))
+    sa.close()
