@@ -412,3 +412,26 @@ def test_run_sequence_fixture_end_to_end(tmp_path, golden_dir, colour):
     stamps, T = tum.read_tum_trajectory(tmp_path / "report.txt")
     np.testing.assert_allclose(T, np.array(rep["estimated_poses_matrix"]).reshape(10, 4, 4), atol=1e-5)
     assert len(stamps) == 10
+
+
+def test_persistent_small_level_kernel_vs_per_iteration_launches(vga_stream, monkeypatch):
+    """The coarse levels (<= 160x120) run in one persistent launch per batch (k_gn_small), a workgroup per pair; with
+    DVO_SMALL_MAX_PIX=0 every level takes the per-iteration launches (k_reduce + k_solve).  Same per-record arithmetic,
+    different summation grouping (the float32 per-lane pre-sums cover different records): poses agree to ~1e-9, for every workgroup width, weighting and
+    variant, and iteration counts are equal."""
+    from dvo_amd.batch import BatchAligner
+    st = vga_stream
+    for kw in (dict(), dict(weighting="huber"), dict(weighting="student_t_reference"), dict(approximate_image2_gradient=True)):
+        out = []
+        for env in ({"DVO_SMALL_MAX_PIX": "0"}, {"DVO_SMALL_THREADS": "256"}, {"DVO_SMALL_THREADS": "512"},
+                    {"DVO_SMALL_THREADS": "1024"}, {}):
+            for k in ("DVO_SMALL_MAX_PIX", "DVO_SMALL_THREADS"):
+                monkeypatch.delenv(k, raising=False)
+            for k, v in env.items():
+                monkeypatch.setenv(k, v)
+            al = BatchAligner(st["K"], st["depth_scale"], 640, 480, 4, max_pairs=8, max_iterations=6, **kw)
+            out.append(al.align_host(st["gray"], st["depth"]))
+            al.close()
+        for o in out[1:]:
+            assert np.array_equal(o["iters"], out[0]["iters"])
+            np.testing.assert_allclose(o["xi"], out[0]["xi"], rtol=0, atol=1e-8)      # measured: 1.3e-9
