@@ -1070,7 +1070,10 @@ static int record_solve(dvo_ctx* ctx, const SolveKey& k, const float* d_init)
         DvoSmallParams sp;
         memset(&sp, 0, sizeof(sp));
         int n = 0;
-        while (level - n >= 0 && n < DVO_SMALL_LEVELS && g[level - n].npix <= ctx->knobs.small_max_pix) {
+        // a handful of pairs cannot fill the chip either way: there a 160x120 level (13 k records) is faster spread over its ~19
+        // workgroups than inside one, so only levels up to 80x60 go to the persistent kernel (single pair: 0.87 -> 0.77 ms)
+        const int max_pix = (n_pairs <= 16) ? (ctx->knobs.small_max_pix < 4800 ? ctx->knobs.small_max_pix : 4800) : ctx->knobs.small_max_pix;
+        while (level - n >= 0 && n < DVO_SMALL_LEVELS && g[level - n].npix <= max_pix) {
             sp.level_id[n] = level - n;
             sp.g[n] = g[level - n];
             sp.cam[n] = level_camera(ctx, level - n);
