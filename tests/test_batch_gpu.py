@@ -435,3 +435,52 @@ def test_persistent_small_level_kernel_vs_per_iteration_launches(vga_stream, mon
         for o in out[1:]:
             assert np.array_equal(o["iters"], out[0]["iters"])
             np.testing.assert_allclose(o["xi"], out[0]["xi"], rtol=0, atol=2e-7)      # measured: up to 2.8e-8
+
+
+def test_run_sequence_on_a_tum_layout_dataset(tmp_path):
+    """tools/run_sequence.py --tum-dir on a TUM-RGB-D-layout dataset written to disk (rgb/*.png, depth/*.png 16-bit, rgb.txt /
+    depth.txt / groundtruth.txt with unsynchronised stamps, camera yaml): association as src/test_dvo.py:113-170, PNG
+    decoding in the decoder pool, batched colour ingest, device solve, report + TUM trajectory.  The frames are a rendered
+    stream with known poses, so the trajectory error checks the whole chain; also through the rank launcher (--spawn)."""
+    import json
+    import subprocess
+    import sys
+    from pathlib import Path
+    from PIL import Image
+    from dvo_amd import synthetic, tum
+    root = Path(__file__).resolve().parents[1]
+    n = 14
+    st = synthetic.make_stream(n, 640, 480, seed=21, device="cuda")
+    data = tmp_path / "rgbd_dataset_synthetic"
+    (data / "rgb").mkdir(parents=True)
+    (data / "depth").mkdir()
+    t0 = 1305031102.0
+    with (data / "rgb.txt").open("w") as fr, (data / "depth.txt").open("w") as fd, (data / "groundtruth.txt").open("w") as fg:
+        fr.write("# color images\n# file: 'synthetic'\n# timestamp filename\n")
+        fd.write("# depth maps\n# timestamp filename\n")
+        fg.write("# ground truth trajectory\n# timestamp tx ty tz qx qy qz qw\n")
+        for k in range(n):
+            tr, td = t0 + k / 30.0, t0 + k / 30.0 + 0.004            # depth lags the colour image by 4 ms, as on a Kinect
+            Image.fromarray(np.repeat(st["gray"][k][..., None], 3, axis=2)).save(data / "rgb" / ("%.6f.png" % tr))
+            Image.fromarray(st["depth"][k].astype(np.uint16)).save(data / "depth" / ("%.6f.png" % td))
+            fr.write("%.6f rgb/%.6f.png\n" % (tr, tr))
+            fd.write("%.6f depth/%.6f.png\n" % (td, td))
+            q = tum.matrix_to_quat_xyzw(st["T_wc"][k][:3, :3])
+            fg.write("%.6f %r %r %r %r %r %r %r\n" % ((tr + 0.002,) + tuple(float(v) for v in st["T_wc"][k][:3, 3]) + tuple(float(v) for v in q)))
+    cam = tmp_path / "camera.yaml"
+    K = np.asarray(st["K"], dtype=np.float64)
+    cam.write_text("intrinsics:\n" + "".join("  - [%r, %r, %r]\n" % tuple(float(v) for v in row) for row in K) +
+                   "depth_scale: %r\n" % float(st["depth_scale"]))
+    for extra in ([], ["--gpus", "1", "--spawn"]):
+        out_dir = tmp_path / ("out%d" % len(extra))
+        cmd = [sys.executable, str(root / "tools" / "run_sequence.py"), "--tum-dir", str(data), "--camera", str(cam),
+               "--out", str(out_dir), "--window", "5", "--decoders", "4"] + extra
+        out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=str(root))
+        assert out.returncode == 0, out.stderr[-3000:]
+        line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+        assert line["type"] == "TUM" and line["frames"] == n and line["input"] == "bgr"
+        assert line["ate_rmse_m"] < 2e-3 and line["rpe_trans_rmse_m"] < 5e-4        # ~1 cm steps recovered to a few 0.01 mm each
+        rep = json.loads((out_dir / "report.json").read_text())
+        assert len(rep["estimated_poses"]) == n and abs(rep["timestamps"][3] - (t0 + 3 / 30.0 + 0.002)) < 1e-5
+        stamps, T = tum.read_tum_trajectory(out_dir / "report.txt")
+        assert len(stamps) == n and np.abs(T[0] - st["T_wc"][0]).max() < 1e-5
