@@ -154,6 +154,44 @@ def align_windows(aligner, windows: Iterable[Tuple[np.ndarray, np.ndarray, int]]
             "err": np.concatenate(errs) if errs else np.zeros(0), "seconds": time.perf_counter() - t0}
 
 
+def align_shard(make_aligner: Callable, source: Callable, n_total: int, rank: int, world: int, window_pairs: int,
+                colour: bool, alloc: Callable = None, workers: int = 0, streams: int = 1):
+    """BASELINE config 4, one rank's part: rank `rank` of `world` aligns the contiguous range of pairs `shard_pairs` gives it
+    (frames lo..hi: one boundary frame is shared with the neighbouring rank).  `source(lo, hi)` yields the frames (or decoder
+    thunks) lo..hi-1; `make_aligner(height, width, window_pairs)` builds the aligner once the frame size is known.
+    -> dict(T, iters, err, seconds, decode_seconds, lo, hi)"""
+    from .batch import shard_pairs
+    lo, hi = shard_pairs(n_total - 1, rank, world)
+    out = {"T": np.zeros((0, 3, 4), np.float32), "iters": np.zeros(0, np.int32), "err": np.zeros(0), "seconds": 0.0,
+           "decode_seconds": 0.0, "lo": lo, "hi": hi}
+    if hi <= lo:
+        return out
+    first = next(iter(source(lo, lo + 1)))
+    first = first() if callable(first) else first
+    h, w = first[1].shape
+    window = max(streams, min(window_pairs, hi - lo))
+    aligner = make_aligner(h, w, window)
+    try:
+        windows = FrameWindows(source(lo, hi + 1), window, alloc=alloc, workers=workers)
+        res = align_windows(aligner, windows, colour)
+    finally:
+        if hasattr(aligner, "close"):
+            aligner.close()
+    out.update(res)
+    out["decode_seconds"] = windows.decode_seconds
+    return out
+
+
+def gather_shards(T_rel: np.ndarray, iters: np.ndarray, n_total: int, device=None):
+    """All ranks contribute the pose records of their pair range; every rank gets the sequence's records in pair order."""
+    import torch.distributed as dist
+    from .batch import shard_pairs, pose_records, allgather_poses
+    world = dist.get_world_size()
+    counts = [shard_pairs(n_total - 1, r, world)[1] - shard_pairs(n_total - 1, r, world)[0] for r in range(world)]
+    rec = allgather_poses(pose_records(T_rel, iters), counts, device=device)
+    return rec[:, :12].reshape(-1, 3, 4), rec[:, 12]
+
+
 def _align_bgr(aligner, bgr, depth, max_distance):
     aligner.ingest_host_bgr(bgr, depth, max_distance)
     aligner.solve_enqueue(bgr.shape[0])

@@ -102,3 +102,70 @@ def test_allgather_poses_gloo(tmp_path, golden_dir, world):
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
     for r in range(world):
         assert "rank %d ok" % r in out.stdout
+
+
+_SHARD_WORKER = r'''
+import os, sys
+import numpy as np
+import torch.distributed as dist
+sys.path.insert(0, os.environ["DVO_PKG_DIR"])
+from dvo_amd import sequence
+from dvo_amd.batch import shard_pairs
+
+dist.init_process_group(backend="gloo")
+rank, world = dist.get_rank(), dist.get_world_size()
+f = np.load(os.environ["DVO_FRAMES"])
+g = np.load(os.environ["DVO_GOLDEN"])
+grays, depths = f["gray"], f["depth"]
+n_total = grays.shape[0]
+key = {int(grays[k].astype(np.int64).sum()): k for k in range(n_total)}           # frame content -> frame index
+calls = []
+
+
+class FakeAligner:
+    """Stands in for the GPU aligner: recognises the frames of a window by content and returns the reference run's own
+    transforms for their pairs, so the test pins the data flow (ranges, windows, carry frames, gather order), not the kernels."""
+    def align_host(self, gray, depth):
+        idx = [key[int(gray[k].astype(np.int64).sum())] for k in range(gray.shape[0])]
+        assert idx == list(range(idx[0], idx[0] + len(idx))), idx
+        assert all(np.array_equal(depth[k], depths[i]) for k, i in enumerate(idx))
+        calls.append(idx)
+        T = np.stack([g["tf_T"][i + 1][:3, :] for i in idx[:-1]]).astype(np.float32)
+        return {"T": T, "iters": np.array(idx[:-1], dtype=np.int32), "err": np.zeros(len(idx) - 1)}
+    def close(self):
+        calls.append("closed")
+
+
+def source(lo, hi):
+    for k in range(lo, hi):
+        yield (lambda k=k: (grays[k], depths[k])) if k % 2 else (grays[k], depths[k])   # decoder thunks and plain frames mixed
+
+res = sequence.align_shard(lambda h, w, win: FakeAligner(), source, n_total, rank, world, window_pairs=2, colour=False, workers=2)
+lo, hi = shard_pairs(n_total - 1, rank, world)
+assert (res["lo"], res["hi"]) == (lo, hi) and res["T"].shape[0] == hi - lo and calls[-1] == "closed"
+assert [c[0] for c in calls[:-1]] == list(range(lo, hi, 2))                      # windows of 2 pairs, sharing their boundary frame
+T_all, iters_all = sequence.gather_shards(res["T"], res["iters"], n_total)
+assert np.array_equal(iters_all, np.arange(n_total - 1, dtype=np.float32))       # pair order preserved across ranks
+report, traj = sequence.build_report("TEST", T_all, g["pose_T"][0].astype(np.float64), f["gt_T"], np.arange(float(n_total)))
+assert np.abs(traj - g["pose_T"]).max() < 5e-6
+assert abs(report["ate_rmse_m"] - 4.1317e-3) < 1e-6
+dist.barrier()
+dist.destroy_process_group()
+print("rank %d ok" % rank)
+'''
+
+
+@pytest.mark.parametrize("world", [1, 2, 3])
+def test_sharded_sequence_flow_gloo(tmp_path, golden_dir, world):
+    """BASELINE config 4 on CPU: every rank aligns its contiguous range of pairs in windows (decoder pool, carry frames), the pose
+    records are all-gathered (gloo here, RCCL on the GPUs) and the composed trajectory equals the reference run's."""
+    script = tmp_path / "shard_worker.py"
+    script.write_text(_SHARD_WORKER)
+    env = dict(os.environ, DVO_PKG_DIR=str(ROOT / "dense-visual-odometry_amd"), DVO_GOLDEN=str(golden_dir / "sequence.npz"),
+               DVO_FRAMES=str(golden_dir / "frames.npz"), OMP_NUM_THREADS="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), str(script)]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+    for r in range(world):
+        assert "rank %d ok" % r in out.stdout

@@ -60,7 +60,7 @@ def main():
             raise SystemExit("run_sequence.py: %s" % e)
 
     from dvo_amd import synthetic, tum, sequence, _cabi, RGBDCameraModel
-    from dvo_amd.batch import StreamedAligner, shard_pairs, pose_records, allgather_poses
+    from dvo_amd.batch import StreamedAligner
 
     rank, local_rank, world = launch.rank_env()
     use_dist = launch.started_by_launcher() or os.environ.get("DVO_FORCE_DIST") == "1"
@@ -107,21 +107,13 @@ def main():
             for k in range(lo, hi):
                 yield (lambda k=k: tum.read_frame(seq.rgb_paths[k], seq.depth_paths[k]))
 
-    lo, hi = shard_pairs(n_total - 1, rank, world) if use_dist else (0, n_total - 1)
-    n_local = hi - lo                                # pairs lo..hi-1 need frames lo..hi (one duplicated boundary frame per rank)
-    res = {"T": np.zeros((0, 3, 4), np.float32), "iters": np.zeros(0, np.int32), "seconds": 0.0}
-    decode_s = 0.0
-    if n_local > 0:
-        first = next(iter(source(lo, lo + 1)))
-        first = first() if callable(first) else first
-        h, w = first[1].shape
-        window = max(args.streams, min(args.window, n_local))
-        al = StreamedAligner(K, scale, w, h, args.levels, max_pairs=window, n_streams=args.streams, device=local_rank,
-                             max_iterations=args.iterations, weighting=args.weighting)
-        windows = sequence.FrameWindows(source(lo, hi + 1), window, alloc=_cabi.pinned_array, workers=args.decoders)
-        res = sequence.align_windows(al, windows, colour)
-        decode_s = windows.decode_seconds
-        al.close()
+    def make_aligner(h, w, window):
+        return StreamedAligner(K, scale, w, h, args.levels, max_pairs=window, n_streams=args.streams, device=local_rank,
+                               max_iterations=args.iterations, weighting=args.weighting)
+
+    res = sequence.align_shard(make_aligner, source, n_total, rank if use_dist else 0, world if use_dist else 1, args.window,
+                               colour, alloc=_cabi.pinned_array, workers=args.decoders, streams=args.streams)
+    n_local, decode_s = res["hi"] - res["lo"], res["decode_seconds"]
     T_rel, iters = res["T"], res["iters"]
 
     if use_dist:
@@ -130,9 +122,7 @@ def main():
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
         if dist.get_world_size() != world:
             raise SystemExit("run_sequence.py: %d ranks joined, %d expected" % (dist.get_world_size(), world))
-        counts = [shard_pairs(n_total - 1, r, world)[1] - shard_pairs(n_total - 1, r, world)[0] for r in range(world)]
-        rec = allgather_poses(pose_records(T_rel, iters), counts, device="cuda")
-        T_rel, iters = rec[:, :12].reshape(-1, 3, 4), rec[:, 12]
+        T_rel, iters = sequence.gather_shards(T_rel, iters, n_total, device="cuda")
         dist.barrier()
         if rank != 0:
             dist.destroy_process_group()
