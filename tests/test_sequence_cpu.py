@@ -86,3 +86,36 @@ def test_report_has_the_references_shape(tmp_path, golden_dir):
     np.testing.assert_allclose(T, traj, atol=1e-5)          # (the float32 ground-truth start pose is orthonormal to ~3e-6 only)
     r2, _ = sequence.build_report("X", T_rel, None, None, np.arange(10.0))
     assert r2["errors"] == ["N/A"] * n and "ate_rmse_m" not in r2
+
+
+def test_windows_and_shards_cover_any_sequence_exactly_once():
+    """Property (hypothesis): for any sequence length, window size, ring depth, decoder-pool size and world size, the pairs seen by
+    all ranks' windows are exactly the pairs of the sequence, each once, in order within a rank."""
+    from hypothesis import given, settings, strategies as st
+    from dvo_amd.batch import shard_pairs
+
+    @settings(max_examples=60, deadline=None)
+    @given(n=st.integers(2, 40), window=st.integers(1, 9), ring=st.integers(2, 4), workers=st.integers(0, 3),
+           world=st.integers(1, 5))
+    def check(n, window, ring, workers, world):
+        seen = []
+        for rank in range(world):
+            lo, hi = shard_pairs(n - 1, rank, world)
+            if hi <= lo:
+                continue
+
+            def frames(lo=lo, hi=hi):
+                for k in range(lo, hi + 1):
+                    item = (np.full((2, 3), k % 251, dtype=np.uint8), np.full((2, 3), k, dtype=np.uint16))
+                    yield (lambda item=item: item) if k % 3 == 0 else item
+
+            mine = []
+            for img, dep, m in sequence.FrameWindows(frames(), window, ring=ring, workers=workers):
+                ids = [int(dep[k, 0, 0]) for k in range(m)]
+                assert ids == list(range(ids[0], ids[0] + m)) and all(int(img[k, 0, 0]) == ids[k] % 251 for k in range(m))
+                mine += [(a, a + 1) for a in ids[:-1]]
+            assert mine == [(a, a + 1) for a in range(lo, hi)]
+            seen += mine
+        assert seen == [(a, a + 1) for a in range(n - 1)]
+
+    check()
