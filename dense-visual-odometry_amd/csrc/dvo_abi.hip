@@ -652,6 +652,7 @@ int dvo_upload_frames(dvo_ctx* ctx, int n_frames, const int* slots, const uint8_
     const size_t npx = (size_t)w * h, need = align_up(npx * n_frames, 256) + npx * n_frames * 2 + 256;
     if (need > ctx->batch_stage_bytes) {
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        if (ctx->upload_peer) HIP_TRY(ctx, hipStreamSynchronize(ctx->upload_peer->copy_stream));   // copies into the old area may be in flight
         if (ctx->d_batch_stage) (void)hipFree(ctx->d_batch_stage);
         ctx->d_batch_stage = nullptr;
         ctx->batch_stage_bytes = 0;

@@ -76,6 +76,16 @@ class FrameWindows:
         for i in range(self._ring):
             self._free.put(i)
 
+    def _put(self, item) -> bool:
+        """queue.put that gives up when the consumer has gone away (it stopped iterating early)."""
+        while not self._stop:
+            try:
+                self._q.put(item, timeout=0.1)
+                return True
+            except queue.Full:
+                continue
+        return False
+
     def _fill(self):
         try:
             carry = None
@@ -105,11 +115,12 @@ class FrameWindows:
                     db[k] = dep
                 carry = (ib[len(items) - 1].copy(), db[len(items) - 1].copy())       # the next window may land in another slot
                 self.decode_seconds += time.perf_counter() - t0
-                self._q.put((slot, len(items)))
+                if not self._put((slot, len(items))):
+                    break
         except BaseException as e:                  # surfaced in the consumer thread
             self._err = e
         finally:
-            self._q.put(None)
+            self._put(None)
 
     def __iter__(self) -> Iterator[Tuple[np.ndarray, np.ndarray, int]]:
         if self._started:

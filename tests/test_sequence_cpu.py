@@ -119,3 +119,17 @@ def test_windows_and_shards_cover_any_sequence_exactly_once():
         assert seen == [(a, a + 1) for a in range(n - 1)]
 
     check()
+
+
+def test_frame_windows_decoder_thread_ends_when_the_consumer_stops_early():
+    import threading
+    import time
+    fw = sequence.FrameWindows(_frames(200), 2)
+    it = iter(fw)
+    next(it)
+    it.close()                                    # consumer walks away after one window
+    deadline = time.time() + 5.0
+    while fw._thread.is_alive() and time.time() < deadline:
+        time.sleep(0.05)
+    assert not fw._thread.is_alive()
+    assert threading.active_count() < 20
