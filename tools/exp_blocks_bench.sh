@@ -1,0 +1,12 @@
+#!/bin/bash
+# Workgroups per launch of the reduction (DVO_TARGET_BLOCKS / DVO_MAX_GROUPS), measured on the whole default job (4 streams).
+for cfg in "default default" "1024 24" "1024 32" "1024 48" "1280 64" "640 128" "2560 32" "default default"; do
+  set -- $cfg
+  if [ "$1" = default ]; then unset DVO_TARGET_BLOCKS DVO_MAX_GROUPS; else export DVO_TARGET_BLOCKS=$1 DVO_MAX_GROUPS=$2; fi
+  python bench.py --steps 10 --warmup 2 --no-cpu-baseline 2>/dev/null | python -c "
+import sys, json
+d = json.loads(sys.stdin.read().strip().splitlines()[-1])
+r = d['roofline']
+print('target $1 maxg $2: %.0f pairs/s  L0 %.1f us  levels %s' % (d['value'], r['avg_launch_us'], ' '.join(('%.1f' % v['avg_us']) if v['avg_us'] else '-' for v in r['per_level'].values())))
+" | tee -a gpurun_out/exp_blocks.log
+done
