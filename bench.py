@@ -55,7 +55,7 @@ def parse_args():
     ap.add_argument("--levels", type=int, default=4)
     ap.add_argument("--iterations", type=int, default=10)
     ap.add_argument("--weighting", default="none", choices=["none", "student_t_reference", "student_t", "huber"])
-    ap.add_argument("--variant", default="v1", choices=["v1", "v2", "v3"],
+    ap.add_argument("--variant", default="v1", choices=["v1", "v2", "v3", "gn"],
                     help="v1: reference CPU default (the metric); v2: approximate_image2_gradient; v3: numba.cuda kernel semantics")
     ap.add_argument("--streams", type=int, default=4, help="independent HIP streams (sub-batches) per GPU")
     ap.add_argument("--distinct", type=int, default=0, help="distinct rendered frames (0 = batch+1)")
@@ -231,7 +231,7 @@ def main():
     al = StreamedAligner(st["K"], st["depth_scale"], W, H, L, max_pairs=B, n_streams=args.streams, device=local_rank,
                          max_iterations=args.iterations, weighting=args.weighting,
                          approximate_image2_gradient=(args.variant == "v2"),
-                         reference_variant="cuda" if args.variant == "v3" else "cpu")
+                         reference_variant={"v3": "cuda", "gn": "gn"}.get(args.variant, "cpu"))
     if use_dist:
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
         world = dist.get_world_size()                      # the ranks that actually joined

@@ -928,8 +928,8 @@ static int stage_pairs(dvo_ctx* ctx, int n_pairs, const int* prev_slot, const in
 
 static int check_variant(dvo_ctx* ctx, int variant)
 {
-    if (variant != DVO_VARIANT_V1 && variant != DVO_VARIANT_V2 && variant != DVO_VARIANT_V3)
-        return fail(ctx, DVO_ERR_INVALID_ARG, "variant %d unknown (V1=0, V2=1, V3=2)", variant);
+    if (variant != DVO_VARIANT_V1 && variant != DVO_VARIANT_V2 && variant != DVO_VARIANT_V3 && variant != DVO_VARIANT_GN)
+        return fail(ctx, DVO_ERR_INVALID_ARG, "variant %d unknown (V1=0, V2=1, V3=2, GN=3)", variant);
     return DVO_OK;
 }
 

@@ -673,7 +673,8 @@ __device__ __forceinline__ float dvo_div_with_rcp(float a, float b, float rb)
 
 // SKEW = false: the camera matrix has no skew term (K[0][1] == 0), so the zero products of the reference's matrix
 // expressions are skipped: x + (+-0) == x, exact.
-template <bool SKEW>
+// WARPED (variant GN): the point handed to the Jacobian is the WARPED one, (x'/z', y'/z', z').
+template <bool SKEW, bool WARPED = false>
 __device__ __forceinline__ void dvo_geo(const DvoLevelGeom& g, const DvoLevelCam& cam, const float* __restrict__ T,
                                         float u, float v, float z, bool live, PixelGeo& o)
 {
@@ -707,7 +708,9 @@ __device__ __forceinline__ void dvo_geo(const DvoLevelGeom& g, const DvoLevelCam
     const bool ok = (int)live & (int)(__float_as_uint(uw) <= __float_as_uint(g.wmax_f)) & (int)(__float_as_uint(vw) <= __float_as_uint(g.hmax_f));
     // v_fract_f32 = c - floor(c), exact; floor(c) = c - fract(c), exact as well
     const float ax = __builtin_amdgcn_fractf(uw), ay = __builtin_amdgcn_fractf(vw);
-    o.x = xn; o.y = yn; o.z = z; o.uw = uw; o.vw = vw; o.ax = ax; o.ay = ay; o.ok = ok;
+    if (WARPED) { o.x = xp * rz; o.y = yp * rz; o.z = zp; }
+    else { o.x = xn; o.y = yn; o.z = z; }
+    o.uw = uw; o.vw = vw; o.ax = ax; o.ay = ay; o.ok = ok;
     // tap offset y0 * pitch + x0, formed in float32 (exact: < 2^24) to save a conversion and an integer multiply
     o.off = ok ? (unsigned)fmaf(vw - ay, g.pitch_f, uw - ax) : 0u;
 }
@@ -770,7 +773,9 @@ __device__ __forceinline__ void dvo_geo_v3(const DvoLevelGeom& g, const DvoLevel
 
 // Phase B: bilinear photometric lookup, residual, 1x6 Jacobian row.
 // VARIANT 0 (V1): gradient of I2 sampled at the warped point; 1 (V2): Sobel gradient of I1 at the pixel;
-// 2 (V3): Jacobian row already finished by dvo_geo_v3, only the residual is computed here.
+// 2 (V3): Jacobian row already finished by dvo_geo_v3, only the residual is computed here;
+// 3 (GN, build-defined): V1's sampling with the Sobel response normalised (1/8: a unit derivative) and J_w at the warped
+// point (dvo_geo<.., true>), i.e. the true Gauss-Newton row of the forward-compositional photometric error.
 template <int VARIANT, bool NEED_J>
 __device__ __forceinline__ void dvo_finish(const DvoLevelCam& cam, const PixelGeo& q, const PixelTaps& t,
                                            unsigned i1, PixelOut& o)
@@ -788,7 +793,7 @@ __device__ __forceinline__ void dvo_finish(const DvoLevelCam& cam, const PixelGe
     o.r = i2 - (float)i1;                                                       // :191-194
     if (!NEED_J || VARIANT == 2) return;        // V3: the Jacobian row was finished in phase A (dvo_geo_v3)
     float gxw, gyw;
-    if (VARIANT == 0) {
+    if (VARIANT == 0 || VARIANT == 3) {
         gxw = fmaf(w11, gx11, fmaf(w10, gx10, fmaf(w01, gx01, w00 * gx00)));    // :123-128
         gyw = fmaf(w11, gy11, fmaf(w10, gy10, fmaf(w01, gy01, w00 * gy00)));
     } else {
@@ -800,7 +805,8 @@ __device__ __forceinline__ void dvo_finish(const DvoLevelCam& cam, const PixelGe
     // both within 2e-7 relative of the reference's float32 quotients, far inside the 1e-5 bound on the increments.
     const float iz = __builtin_amdgcn_rcpf(q.z);
     const float a = q.x, b = q.y;
-    const float p = cam.fx * gxw, qq = cam.fy * gyw;
+    const float jfx = (VARIANT == 3) ? cam.fx * 0.125f : cam.fx, jfy = (VARIANT == 3) ? cam.fy * 0.125f : cam.fy;   // wave-uniform
+    const float p = jfx * gxw, qq = jfy * gyw;
     // J = gx * Jw[0,:] + gy * Jw[1,:]   (_fill_jacobian, cpu_robust...:79-90), with the common factor m = p a + q b taken out:
     //   -(p ab + q (1 + b^2)) = -(b m + q),   p (1 + a^2) + q ab = a m + p        (11 instructions instead of 16)
     const float m = fmaf(p, a, qq * b);
@@ -1018,7 +1024,7 @@ __global__ __launch_bounds__(DVO_BLOCK, (VARIANT == 2) ? 2 : DVO_REDUCE_WAVES_PE
                 const unsigned d = live ? (unsigned)depth_prev[yi * (unsigned)p.g.w + xi] : 0u;
                 dvo_geo_v3(p.g, cam, p.depth_scale, T, gray_prev, (int)xi, (int)yi, d, geo[j], jv3[j]);
             } else {
-                dvo_geo<SKEW>(p.g, cam, T, (float)xi, (float)yi, __uint_as_float(rc[j].x), live, geo[j]);
+                dvo_geo<SKEW, VARIANT == 3>(p.g, cam, T, (float)xi, (float)yi, __uint_as_float(rc[j].x), live, geo[j]);
             }
             dvo_load_taps(p.g, packed_cur, geo[j], taps[j]);
             if (VARIANT == 1) taps[j].own = geo[j].ok ? packed_prev[yi * (unsigned)p.g.pitch + xi] : 0u;
@@ -1173,6 +1179,10 @@ static hipError_t launch_reduce_v(const DvoReduceParams& p, int weight_mode, int
 hipError_t dvo_launch_reduce(const DvoReduceParams& p, int variant, int weight_mode, int scale_pass, hipStream_t s)
 {
     if (variant == 2) return launch_reduce_v<2, 0, false>(p, weight_mode, scale_pass, s);      // V3: no per-level kernel tags
+    if (variant == 3) {                         // GN: no per-level kernel tags either
+        if (!p.cam.skew0) return launch_reduce_v<3, 0, true>(p, weight_mode, scale_pass, s);
+        return launch_reduce_v<3, 0, false>(p, weight_mode, scale_pass, s);
+    }
     if (!p.cam.skew0) {                         // cameras with a skew term: general expressions, no per-level tags
         if (variant == 0) return launch_reduce_v<0, 0, true>(p, weight_mode, scale_pass, s);
         return launch_reduce_v<1, 0, true>(p, weight_mode, scale_pass, s);
@@ -1257,8 +1267,8 @@ __global__ __launch_bounds__(DVO_BLOCK) void k_dense(const DvoDenseParams p)
         if constexpr (VARIANT == 2) dvo_geo_v3(p.g, p.cam, p.depth_scale, T, gray_prev, ux, vy, d, q, jpre);
         else {
             const float z = (float)((double)d * p.depth_scale);               // camera_model.py:200-201
-            if (p.cam.skew0) dvo_geo<false>(p.g, p.cam, T, (float)ux, (float)vy, z, true, q);
-            else dvo_geo<true>(p.g, p.cam, T, (float)ux, (float)vy, z, true, q);
+            if (p.cam.skew0) dvo_geo<false, VARIANT == 3>(p.g, p.cam, T, (float)ux, (float)vy, z, true, q);
+            else dvo_geo<true, VARIANT == 3>(p.g, p.cam, T, (float)ux, (float)vy, z, true, q);
         }
         if (q.ok) {
             PixelTaps t;
@@ -1285,6 +1295,7 @@ hipError_t dvo_launch_dense(const DvoDenseParams& p, int variant, hipStream_t s)
     dim3 grid((p.g.npix + DVO_BLOCK - 1) / DVO_BLOCK), block(DVO_BLOCK);
     if (variant == 0) hipLaunchKernelGGL(k_dense<0>, grid, block, 0, s, p);
     else if (variant == 1) hipLaunchKernelGGL(k_dense<1>, grid, block, 0, s, p);
+    else if (variant == 3) hipLaunchKernelGGL(k_dense<3>, grid, block, 0, s, p);
     else hipLaunchKernelGGL(k_dense<2>, grid, block, 0, s, p);
     return hipGetLastError();
 }
@@ -1831,7 +1842,7 @@ __device__ __forceinline__ void wave_reduce_terms(const float* acc, float* wbuf 
 template <int VARIANT, int WMODE, bool SKEW>
 __global__ __launch_bounds__(DVO_SMALL_MAX_THREADS) void k_gn_small(const DvoSmallParams p)
 {
-    static_assert(VARIANT == 0 || VARIANT == 1, "V3 keeps the per-iteration launches");
+    static_assert(VARIANT == 0 || VARIANT == 1 || VARIANT == 3, "V3 keeps the per-iteration launches");
     __shared__ DvoPairState st;
     __shared__ float T_sh[12];
     __shared__ int active_sh;
@@ -1902,7 +1913,7 @@ __global__ __launch_bounds__(DVO_SMALL_MAX_THREADS) void k_gn_small(const DvoSma
                             for (int j = 0; j < DVO_PX_PER_THREAD; ++j) {
                                 const bool live = (seg + j * 64 + lane_) < count;
                                 const unsigned pix = rc[j].y;
-                                dvo_geo<SKEW>(g, cam, T, (float)(pix & 0xfffu), (float)((pix >> 12) & 0xfffu), __uint_as_float(rc[j].x), live, geo[j]);
+                                dvo_geo<SKEW, VARIANT == 3>(g, cam, T, (float)(pix & 0xfffu), (float)((pix >> 12) & 0xfffu), __uint_as_float(rc[j].x), live, geo[j]);
                                 dvo_load_taps(g, packed_cur, geo[j], taps[j]);
                                 taps[j].own = 0u;
                             }
@@ -1963,7 +1974,7 @@ __global__ __launch_bounds__(DVO_SMALL_MAX_THREADS) void k_gn_small(const DvoSma
                     const bool live = (seg + j * 64 + lane_) < count;
                     const unsigned pix = rc[j].y;
                     const unsigned xi = pix & 0xfffu, yi = (pix >> 12) & 0xfffu;
-                    dvo_geo<SKEW>(g, cam, T, (float)xi, (float)yi, __uint_as_float(rc[j].x), live, geo[j]);
+                    dvo_geo<SKEW, VARIANT == 3>(g, cam, T, (float)xi, (float)yi, __uint_as_float(rc[j].x), live, geo[j]);
                     dvo_load_taps(g, packed_cur, geo[j], taps[j]);
                     taps[j].own = 0u;
                     if (VARIANT == 1) taps[j].own = geo[j].ok ? packed_prev[yi * (unsigned)g.pitch + xi] : 0u;
@@ -2025,6 +2036,7 @@ hipError_t dvo_launch_gn_small(const DvoSmallParams& p, int variant, int threads
     } while (0)
     if (variant == 0) { if (skew) DVO_SMALL_W(0, true); else DVO_SMALL_W(0, false); }
     else if (variant == 1) { if (skew) DVO_SMALL_W(1, true); else DVO_SMALL_W(1, false); }
+    else if (variant == 3) { if (skew) DVO_SMALL_W(3, true); else DVO_SMALL_W(3, false); }
     else return hipErrorInvalidValue;
 #undef DVO_SMALL_W
 #undef DVO_SMALL_LAUNCH

@@ -16,7 +16,7 @@ NE_STRIDE = 32
 TRACE_STRIDE = 50
 MAX_LEVELS = 8
 
-VARIANT_V1, VARIANT_V2, VARIANT_V3 = 0, 1, 2
+VARIANT_V1, VARIANT_V2, VARIANT_V3, VARIANT_GN = 0, 1, 2, 3
 WEIGHT_NONE, WEIGHT_STUDENT_T, WEIGHT_HUBER, WEIGHT_STUDENT_T_MEAN = 0, 1, 2, 3
 
 import os as _os
@@ -104,6 +104,14 @@ def load_library() -> C.CDLL:
         raise ImportError(
             "HIP extension {} is missing — build it with `python __graft_entry__.py` or "
             "`make -C dense-visual-odometry_amd/csrc`; this package has no CPU fallback".format(_LIB_PATH))
+    # One HIP runtime per process: PyTorch-ROCm ships its own libamdhip64 and loads it by path, so when libdvo_hip.so (linked
+    # against the system ROCm) comes first the process ends up with two runtimes and torch.cuda then reports "No HIP GPUs are
+    # available" (measured, tools/order_test.py).  With torch imported first the loader resolves this library's libamdhip64
+    # dependency to the copy already in the process.  Hosts without PyTorch (plain C, or Python without torch) are unaffected.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     lib = C.CDLL(str(_LIB_PATH))
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)          # AttributeError if the .so does not export a declared symbol

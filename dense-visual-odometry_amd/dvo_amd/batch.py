@@ -34,8 +34,12 @@ class BatchAligner:
         self.max_increased = max_increased_steps_allowed
         self.weight_mode, self.huber_k = _WEIGHTS[weighting], huber_k
         self.variant = _cabi.VARIANT_V2 if approximate_image2_gradient else _cabi.VARIANT_V1
+        if reference_variant not in ("cpu", "cuda", "gn"):
+            raise ValueError("reference_variant must be 'cpu', 'cuda' or 'gn', got '{}'".format(reference_variant))
         if reference_variant == "cuda":
             self.variant = _cabi.VARIANT_V3
+        elif reference_variant == "gn":         # build-defined true Gauss-Newton mode (DVO_VARIANT_GN)
+            self.variant = _cabi.VARIANT_GN
         self.ctx = _cabi.HipContext(device=device, max_w=width, max_h=height, max_levels=levels,
                                     n_slots=max_pairs + 1, max_pairs=max_pairs)
         K = np.asarray(K, dtype=np.float32)

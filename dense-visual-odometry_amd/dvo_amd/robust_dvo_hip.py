@@ -38,7 +38,7 @@ class ImagePyramidError(Exception):
     pass
 
 
-_VARIANTS = {"v1": _cabi.VARIANT_V1, "v2": _cabi.VARIANT_V2, "v3": _cabi.VARIANT_V3}
+_VARIANTS = {"v1": _cabi.VARIANT_V1, "v2": _cabi.VARIANT_V2, "v3": _cabi.VARIANT_V3, "gn": _cabi.VARIANT_GN}
 # "student_t_reference": the reference's weighter as written (scale = SUM, quirk Q3: weights ~ 1.2 for every pixel);
 # "student_t": the same weight with the scale taken as the MEAN (build-defined, what the reference intends); "huber": new
 _WEIGHTS = {"none": _cabi.WEIGHT_NONE, "student_t_reference": _cabi.WEIGHT_STUDENT_T, "huber": _cabi.WEIGHT_HUBER,
@@ -93,10 +93,14 @@ class RobustDVOHIP:
         # which of the reference's behaviours to reproduce: "cpu" = RobustDVOCPU (V1, or V2 with
         # approximate_image2_gradient), "cuda" = its numba.cuda kernel (V3: central-difference gradient of I1,
         # J_w at the warped point, strict bilinear bounds, mask = depth-valid AND in bounds)
-        if reference_variant not in ("cpu", "cuda"):
-            raise ValueError("reference_variant must be 'cpu' or 'cuda', got '{}'".format(reference_variant))
+        # "gn" is not a reference behaviour: the build's production mode (DVO_VARIANT_GN: V1 with the gradient normalised and
+        # J_w at the warped point, i.e. full Gauss-Newton steps)
+        if reference_variant not in ("cpu", "cuda", "gn"):
+            raise ValueError("reference_variant must be 'cpu', 'cuda' or 'gn', got '{}'".format(reference_variant))
         if reference_variant == "cuda":
             self._variant = _cabi.VARIANT_V3
+        elif reference_variant == "gn":
+            self._variant = _cabi.VARIANT_GN
         else:
             self._variant = _cabi.VARIANT_V2 if approximate_image2_gradient else _cabi.VARIANT_V1
         if weighting is None:

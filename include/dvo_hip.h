@@ -57,8 +57,12 @@ typedef enum dvo_variant {
     DVO_VARIANT_V1 = 0,  /* CPU default: Sobel grad of I2 sampled at the warped point, J_w at the un-warped
                             point (cpu_robust_dense_visual_odometry.py:58,123-130,168-170) */
     DVO_VARIANT_V2 = 1,  /* approximate_image2_gradient=True: Sobel grad of I1 at the pixel (:60-77,:187-188) */
-    DVO_VARIANT_V3 = 2   /* numba.cuda kernel: central-difference grad of I1, J_w at the WARPED point, strict
+    DVO_VARIANT_V3 = 2,  /* numba.cuda kernel: central-difference grad of I1, J_w at the WARPED point, strict
                             bilinear bounds (cuda/residuals_kernel.py:46-109) */
+    DVO_VARIANT_GN = 3   /* build-defined production mode: V1's residual, validity and sampled Sobel gradient of
+                            I2, with the gradient normalised to a unit derivative (x 1/8) and J_w evaluated at the WARPED point:
+                            a true Gauss-Newton step per iteration instead of V1's 1/8 step with the Jacobian of the un-warped
+                            point (quirks Q1, Q2).  Same cost per iteration as V1; not a reference behaviour (parity unpinned) */
 } dvo_variant;
 
 typedef enum dvo_weight_mode {

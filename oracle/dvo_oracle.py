@@ -227,6 +227,8 @@ def bilinear(image: np.ndarray, u: np.ndarray, v: np.ndarray) -> np.ndarray:
 VARIANT_V1 = "v1"          # CPU default: grad I2 (Sobel) sampled at warped coords, J_w at un-warped p
 VARIANT_V2 = "v2"          # CPU approximate_image2_gradient: grad I1 (Sobel) at the pixel
 VARIANT_V3 = "v3"          # numba.cuda kernel: grad I1 central diff, J_w at WARPED p', strict bounds
+VARIANT_GN = "gn"          # build-defined production mode (no reference counterpart): V1's residual / validity / sampled
+                           # Sobel gradient of I2, normalised (x 1/8), J_w at the WARPED point p' (true Gauss-Newton row)
 
 
 @dataclass
@@ -315,6 +317,17 @@ def residuals_and_jacobian(lv: PairLevel, T: np.ndarray, variant: str = VARIANT_
             lv.gradx, lv.grady = sobel3(lv.gray_cur)                     # _setup :58
         Jw = warp_jacobian(x[ok], y[ok], z[ok], lv.KL)                   # :168-170, :183
         gx = bilinear(lv.gradx, u[ok], v[ok])                            # :123-128
+        gy = bilinear(lv.grady, u[ok], v[ok])
+    elif variant == VARIANT_GN:
+        # PARITY UNPINNED (build-defined, DVO_VARIANT_GN): the warp Jacobian of utils/jacobian.py:39-42 evaluated at the
+        # warped point and multiplied by the unit-derivative gradient, in float64 (the device path is float32)
+        if lv.gradx is None:
+            lv.gradx, lv.grady = sobel3(lv.gray_cur)
+        KL8 = np.array(lv.KL, dtype=np.float64)
+        KL8[0, 0] *= 0.125
+        KL8[1, 1] *= 0.125
+        Jw = warp_jacobian(xp[ok].astype(np.float64), yp[ok].astype(np.float64), zp[ok].astype(np.float64), KL8)
+        gx = bilinear(lv.gradx, u[ok], v[ok])
         gy = bilinear(lv.grady, u[ok], v[ok])
     elif variant == VARIANT_V2:
         g1x, g1y = sobel3(lv.gray_prev)                                  # :69-71

@@ -660,6 +660,60 @@ def test_variant_v3_full_solve_vs_oracle(frames):
     assert mask.sum() == r.shape[0]          # this variant's mask is depth-valid AND in bounds
 
 
+# ------------------------------------------------------------------------------------------------
+# variant GN: build-defined production mode: V1 with the gradient normalised and J_w at the warped point
+# (parity unpinned: no reference counterpart; checked against the oracle's float64 restatement of the same definition)
+# ------------------------------------------------------------------------------------------------
+def test_variant_gn_dense_and_normal_equations_vs_oracle(hip, frames, pyramids):
+    ctx, cabi = hip
+    for lvl, xi in ((0, [0.002, -0.007, -0.011, 0.005, 0.0065, 0.0034]), (2, [0, 0, 0, 0, 0, 0]), (3, [0.01, 0.004, -0.02, -0.01, 0.008, 0.015])):
+        T = O.Pose.from_xi(np.array(xi, dtype=np.float64)).matrix()
+        r, J, valid, uv, (h, w) = ctx.residuals_jacobian(lvl, 0, 1, T, variant=cabi.VARIANT_GN)
+        ro, Jo, mask_o, valid_o = O.residuals_and_jacobian(_level(frames, pyramids, 0, lvl), T, "gn")
+        r1, J1, valid1, _, _ = ctx.residuals_jacobian(lvl, 0, 1, T, variant=cabi.VARIANT_V1)
+        assert np.array_equal(valid.reshape(h, w), valid_o) and np.array_equal(valid, valid1)
+        assert np.array_equal(r[valid], r1[valid1])                              # V1's residual, bit for bit
+        scale = np.abs(Jo).max(axis=0)
+        assert np.all(np.abs(J[valid] - Jo).max(axis=0) <= 3e-6 * scale), np.abs(J[valid] - Jo).max(axis=0) / scale
+        for wm, wp in ((cabi.WEIGHT_NONE, None), (cabi.WEIGHT_HUBER, [10.0])):
+            rec = ctx.normal_equations(lvl, [0], [1], T[None], cabi.VARIANT_GN, wm, wp)[0]
+            H, b, swr2, n, _ = cabi.unpack_record(rec)
+            wts = None if wp is None else O.huber_weights(ro, wp[0])
+            Ho, bo, so, no = O.normal_equations(ro, Jo, wts)
+            assert n == no and _rel(H, Ho) < 2e-6 and _rel(_solve(H, b), O.solve_increment(Ho, bo)) < 1e-5
+
+
+def test_variant_gn_takes_full_gauss_newton_steps(frames):
+    """The point of the mode: the reference's V1 takes 1/8 of a Gauss-Newton step per iteration (unnormalised Sobel, quirk Q1), so
+    at 10 iterations per level it is still short of the minimum; GN gets at least as close in 3.  Device and host solve against
+    the oracle's loop with the same definition on the fixture pair, then against exact ground truth on a rendered pair."""
+    import dvo_amd
+    from dvo_amd import synthetic
+    cam = dvo_amd.RGBDCameraModel(frames["K"], frames["depth_scale"])
+    est = O.gauss_newton(frames["gray"][0], frames["depth"][0], frames["gray"][1], frames["K"], frames["depth_scale"],
+                         levels=4, max_iterations=3, variant="gn")
+    for solver in ("device", "host"):
+        dvo = dvo_amd.get_dvo("robust-dvo", cam, dvo_amd.Se3.identity(), levels=4, solver=solver, reference_variant="gn", max_iterations=3)
+        dvo.step_gray(frames["gray"][0], frames["depth"][0])
+        tf = dvo.step_gray(frames["gray"][1], frames["depth"][1])
+        np.testing.assert_allclose(tf.log().reshape(6), est.log(), rtol=0, atol=5e-6)
+
+    st = synthetic.make_stream(4, 640, 480, seed=11, device="cuda")
+    scam = dvo_amd.RGBDCameraModel(st["K"], st["depth_scale"])
+    errs = {}
+    for name, kw in (("gn3", dict(reference_variant="gn", max_iterations=3)), ("v1_10", dict(max_iterations=10)),
+                     ("v1_3", dict(max_iterations=3))):
+        dvo = dvo_amd.get_dvo("robust-dvo", scam, dvo_amd.Se3.identity(), levels=4, solver="device", **kw)
+        e = []
+        for k in range(4):
+            tf = dvo.step_gray(st["gray"][k], st["depth"][k])
+            if k:
+                rel_gt = np.linalg.inv(st["T_wc"][k]) @ st["T_wc"][k - 1]
+                e.append(float(np.linalg.norm(tf.exp()[:3, 3] - rel_gt[:3, 3])))
+        errs[name] = float(np.mean(e))
+    assert errs["gn3"] < errs["v1_3"] and errs["gn3"] <= 1.05 * errs["v1_10"], errs
+
+
 def test_degenerate_poses_give_empty_systems(hip):
     """NaN / far-away / behind-the-camera poses: every pixel fails the in-bounds test, nothing is read out of bounds,
     the record is exactly zero and the device loop stops after one iteration without touching the pose."""
@@ -718,7 +772,7 @@ def test_fuzz_random_geometry_vs_oracle(seed):
             assert np.array_equal(pts["x"], xs) and np.array_equal(pts["y"], ys)
             assert np.array_equal(pts["intensity"], gp[lvl][ys, xs])
             assert np.array_equal(pts["z"], (dp[lvl][ys, xs].astype(np.float64) * depth_scale).astype(np.float32))
-            for variant, vname in ((_cabi.VARIANT_V1, "v1"), (_cabi.VARIANT_V2, "v2"), (_cabi.VARIANT_V3, "v3")):
+            for variant, vname in ((_cabi.VARIANT_V1, "v1"), (_cabi.VARIANT_V2, "v2"), (_cabi.VARIANT_V3, "v3"), (_cabi.VARIANT_GN, "gn")):
                 if vname == "v3" and skew != 0.0:
                     continue                                   # the numba.cuda kernel has no skew term at all
                 r, J, valid, uv, (hh, ww) = ctx.residuals_jacobian(lvl, 0, 1, T, variant=variant)

@@ -296,6 +296,40 @@ def test_variant_v3_strict_bounds_and_types(golden_dir, frames):
     assert both.sum() > 0.95 * v1.sum() and np.abs(a[both] - b[both]).max() < 0.05
 
 
+def test_variant_gn_is_v1_with_unit_gradients_and_the_warped_point(frames):
+    """GN = the build's production mode (DVO_VARIANT_GN, no reference counterpart; parity unpinned).  What its definition
+    guarantees: V1's residuals and validity; at the identity pose (warped point == un-warped point) exactly 1/8 of V1's
+    Jacobian, hence 8 x V1's increment — V1 takes an eighth of a Gauss-Newton step (quirk Q1); away from the identity the rows
+    differ by J_w's evaluation point only; and the loop gets closer to the minimum in 3 iterations per level than V1 does."""
+    gp, dp, gc = (O.build_pyramid(frames["gray"][0], 4), O.build_pyramid(frames["depth"][0], 4),
+                  O.build_pyramid(frames["gray"][1], 4))
+    lv = O.PairLevel(gp[3], dp[3], gc[3], O.level_intrinsics(frames["K"], 3), frames["depth_scale"])
+    I = np.eye(4, dtype=np.float32)
+    r1, J1, m1, v1 = O.residuals_and_jacobian(lv, I, "v1")
+    rg, Jg, mg, vg = O.residuals_and_jacobian(lv, I, "gn")
+    assert np.array_equal(r1, rg) and np.array_equal(v1, vg) and np.array_equal(m1, mg)
+    np.testing.assert_allclose(Jg * 8.0, J1, rtol=2e-6, atol=1e-3)
+    H1, b1, _, _ = O.normal_equations(r1, J1)
+    Hg, bg, _, _ = O.normal_equations(rg, Jg)
+    np.testing.assert_allclose(O.solve_increment(Hg, bg), 8.0 * O.solve_increment(H1, b1), rtol=1e-5, atol=1e-9)
+    T = O.Pose.from_xi(np.array([0.01, 0.004, -0.02, -0.01, 0.008, 0.015])).matrix()
+    r1, J1, _, _ = O.residuals_and_jacobian(lv, T, "v1")
+    rg, Jg, _, _ = O.residuals_and_jacobian(lv, T, "gn")
+    assert np.array_equal(r1, rg) and not np.allclose(Jg * 8.0, J1, rtol=1e-4)
+    # convergence on the two coarsest levels of the fixture pair (small enough for the CPU suite): final photometric error
+    small = dict(gray_prev=gp[2], depth_prev=dp[2], gray_cur=gc[2], K=O.level_intrinsics(frames["K"], 2)[:3, :3],
+                 depth_scale=frames["depth_scale"], levels=2)
+    errs = {}
+    for name, variant, iters in (("gn3", "gn", 3), ("v1_3", "v1", 3), ("v1_10", "v1", 10)):
+        est = O.gauss_newton(small["gray_prev"], small["depth_prev"], small["gray_cur"], small["K"], small["depth_scale"],
+                             levels=2, max_iterations=iters, variant=variant)
+        lv0 = O.PairLevel(gp[2], dp[2], gc[2], O.level_intrinsics(frames["K"], 2), frames["depth_scale"])
+        r, _, _, _ = O.residuals_and_jacobian(lv0, est.matrix(), "v1")
+        errs[name] = float(np.mean(r.astype(np.float64) ** 2))
+    # (real frames, coarse levels: the two end within a few percent of each other; 3 V1 iterations are nowhere near)
+    assert errs["gn3"] < 0.6 * errs["v1_3"] and errs["gn3"] <= errs["v1_10"] * 1.05, errs
+
+
 def test_cpu_baseline_worker_runs_the_oracle_on_a_sample(tmp_path, frames):
     """oracle/cpu_worker.py (bench.py's CPU-baseline leg, run as plain child processes): same poses as calling the oracle
     directly, and the command-line form prints the seconds of its range."""

@@ -1,0 +1,16 @@
+import sys
+sys.path.insert(0, "dense-visual-odometry_amd")
+import numpy as np
+import dvo_amd
+order = sys.argv[1]
+if order == "torch_first":
+    import torch
+    print("torch sees", torch.cuda.device_count(), torch.zeros(1, device="cuda").item())
+ctx = dvo_amd.HipContext(max_w=64, max_h=48, max_levels=1, n_slots=2, max_pairs=1)
+print("ctx ok")
+import torch
+print("torch after ctx: count", torch.cuda.device_count())
+try:
+    print(torch.zeros(1, device="cuda").item(), "torch cuda ok after ctx")
+except Exception as e:
+    print("FAILED:", repr(e)[:200])
