@@ -638,6 +638,7 @@ struct PixelOut {
 // Phase A of a pixel: geometry up to the in-bounds decision and the tap address (no dependent loads).
 struct PixelGeo {
     float x, y, z;       // back-projected point (un-warped) as (x/z, y/z, z): x/z, y/z are the normalised pixel coordinates
+                         // (variant GN: the warped point as (x'/z', y'/z', 1/z'))
     float uw, vw;        // warped pixel coordinates
     float ax, ay;        // their fractional parts uw - floor(uw), vw - floor(vw) (exact)
     unsigned off;        // offset of tap (y0, x0) in the packed plane (0 when !ok, so the load is harmless)
@@ -708,7 +709,7 @@ __device__ __forceinline__ void dvo_geo(const DvoLevelGeom& g, const DvoLevelCam
     const bool ok = (int)live & (int)(__float_as_uint(uw) <= __float_as_uint(g.wmax_f)) & (int)(__float_as_uint(vw) <= __float_as_uint(g.hmax_f));
     // v_fract_f32 = c - floor(c), exact; floor(c) = c - fract(c), exact as well
     const float ax = __builtin_amdgcn_fractf(uw), ay = __builtin_amdgcn_fractf(vw);
-    if (WARPED) { o.x = xp * rz; o.y = yp * rz; o.z = zp; }
+    if (WARPED) { o.x = xp * rz; o.y = yp * rz; o.z = rz; }      // z slot = 1 / z' (refined reciprocal), used as such by dvo_finish<3>
     else { o.x = xn; o.y = yn; o.z = z; }
     o.uw = uw; o.vw = vw; o.ax = ax; o.ay = ay; o.ok = ok;
     // tap offset y0 * pitch + x0, formed in float32 (exact: < 2^24) to save a conversion and an integer multiply
@@ -803,7 +804,7 @@ __device__ __forceinline__ void dvo_finish(const DvoLevelCam& cam, const PixelGe
     // --- J_w at the UN-warped point (utils/jacobian.py:39-42, quirk Q2) ------------------------------
     // x/z and y/z are the normalised coordinates the point was built from (x = xn * z), and 1/z is v_rcp_f32 (1 ulp):
     // both within 2e-7 relative of the reference's float32 quotients, far inside the 1e-5 bound on the increments.
-    const float iz = __builtin_amdgcn_rcpf(q.z);
+    const float iz = (VARIANT == 3) ? q.z : __builtin_amdgcn_rcpf(q.z);
     const float a = q.x, b = q.y;
     const float jfx = (VARIANT == 3) ? cam.fx * 0.125f : cam.fx, jfy = (VARIANT == 3) ? cam.fy * 0.125f : cam.fy;   // wave-uniform
     const float p = jfx * gxw, qq = jfy * gyw;
