@@ -37,3 +37,16 @@ for k in range(12):
     dvo.step_gray(st["gray"][k], st["depth"][k])
     ts.append(time.perf_counter() - t0)
 print("solver=device, use_weighter=True: step_gray() ms per frame: median %.2f min %.2f" % (1e3 * np.median(ts[1:]), 1e3 * min(ts[1:])))
+# the build's true Gauss-Newton mode, 3 iterations per level
+dvo = dvo_amd.get_dvo("robust-dvo", cam, dvo_amd.Se3.identity(), levels=4, max_iterations=3, solver="device", reference_variant="gn")
+ts = []
+for k in range(12):
+    t0 = time.perf_counter()
+    dvo.step_gray(st["gray"][k], st["depth"][k])
+    ts.append(time.perf_counter() - t0)
+print("solver=device, reference_variant='gn', 3 iterations per level: step_gray() ms per frame: median %.2f min %.2f" % (1e3 * np.median(ts[1:]), 1e3 * min(ts[1:])))
+import cProfile, pstats
+pr = cProfile.Profile(); pr.enable()
+for k in range(24): dvo.step_gray(st["gray"][k % 12], st["depth"][k % 12])
+pr.disable()
+pstats.Stats(pr).sort_stats("cumulative").print_stats(16)
