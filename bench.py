@@ -341,7 +341,7 @@ def main():
                        "gn_iterations_per_s": world * iters_total * args.steps / elapsed,
                        "pose_gather_ms_per_step": (1e3 * gather_s[0] / args.steps) if use_dist else None,
                        "parallelism": "1 independent stream per GPU, RCCL all-gather of pose records"},
-            "roofline": {"bound": "hbm", "limiter_measured": "VALU issue (145 instructions per point-wave at 3.2 cycles each, clock 2.1 GHz in-kernel: 0.62 of the 2-cycle issue roofline), with the HBM stream (`traffic` / launch time) at 0.53 of peak and no wasted re-reads (DESIGN.md section 5)", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "roofline": {"bound": "hbm", "limiter_measured": "VALU issue (145 instructions per point-wave at 3.2 cycles each, clock 2.1 GHz in-kernel: 0.62 of the 2-cycle issue roofline, 0.72 with the instruction mix priced), beside a texture addresser 61 % busy (3.35 vector-memory instructions per point-wave) and an HBM stream (`traffic` / launch time) at 0.53 of peak = 0.67 of the achievable rate with no wasted re-reads (DESIGN.md section 5)", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS,
                          "traffic": (recorded_traffic(npr, W, H) or {}).get("hbm_bytes_per_launch"),
                          "traffic_source": (recorded_traffic(npr, W, H) or {}).get("source"),

@@ -1,3 +1,8 @@
+#!/usr/bin/env python3
+"""Does it matter whether libdvo_hip.so or PyTorch initialises HIP first in a process?  (It did: PyTorch-ROCm loads its own
+libamdhip64 by path, and with the system copy already in the process torch.cuda then finds no GPU; dvo_amd._cabi.load_library
+therefore imports torch before it loads the extension.)
+    python tools/order_test.py ctx_first | torch_first"""
 import sys
 sys.path.insert(0, "dense-visual-odometry_amd")
 import numpy as np
