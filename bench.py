@@ -57,6 +57,7 @@ def parse_args():
     ap.add_argument("--weighting", default="none", choices=["none", "student_t_reference", "student_t", "huber"])
     ap.add_argument("--variant", default="v1", choices=["v1", "v2", "v3", "gn"],
                     help="v1: reference CPU default (the metric); v2: approximate_image2_gradient; v3: numba.cuda kernel semantics")
+    ap.add_argument("--level-iterations", type=str, default=None, help="comma-separated iterations per level, finest first (build-defined schedule; default: --iterations at every level)")
     ap.add_argument("--streams", type=int, default=4, help="independent HIP streams (sub-batches) per GPU")
     ap.add_argument("--distinct", type=int, default=0, help="distinct rendered frames (0 = batch+1)")
     ap.add_argument("--spawn", action="store_true",
@@ -231,7 +232,8 @@ def main():
     al = StreamedAligner(st["K"], st["depth_scale"], W, H, L, max_pairs=B, n_streams=args.streams, device=local_rank,
                          max_iterations=args.iterations, weighting=args.weighting,
                          approximate_image2_gradient=(args.variant == "v2"),
-                         reference_variant={"v3": "cuda", "gn": "gn"}.get(args.variant, "cpu"))
+                         reference_variant={"v3": "cuda", "gn": "gn"}.get(args.variant, "cpu"),
+                         level_iterations=([int(v) for v in args.level_iterations.split(",")] if args.level_iterations else None))
     if use_dist:
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
         world = dist.get_world_size()                      # the ranks that actually joined
@@ -289,12 +291,14 @@ def main():
     prof.ctx.profile_enable(False)
 
     # --- the build's own production mode beside the metric (N = 1, default workload only): true Gauss-Newton steps on the same
-    # kernel (DVO_VARIANT_GN), 3 iterations per level.  Reported under "production_mode"; never `value`.
+    # kernel (DVO_VARIANT_GN), 1 iteration at the finest level and 2 at the others.  Reported under "production_mode"; never `value`.
     gn_mode = None
-    if world == 1 and args.variant == "v1" and args.weighting == "none":
+    if world == 1 and args.variant == "v1" and args.weighting == "none" and not args.level_iterations:
         from dvo_amd import _cabi
+        sched = [1] + [2] * (L - 1)                       # finest level first (tools/exp_gn_schedule.sh)
         for a in al.parts:
-            a.variant, a.max_iterations = _cabi.VARIANT_GN, 3
+            a.variant, a.max_iterations = _cabi.VARIANT_GN, max(sched)
+            a.ctx.set_level_iterations(sched)
         gn_steps = max(1, min(args.steps, 10))
         step()
         fence()
@@ -304,12 +308,13 @@ def main():
         fence()
         tg = time.perf_counter() - tg0
         gn_mode = {"variant": "gn (DVO_VARIANT_GN: V1 with the Sobel response normalised and J_w at the warped point; build-defined, "
-                              "not a reference behaviour)", "gn_iterations_per_level": 3, "frame_pairs_per_s": B * gn_steps / tg,
+                              "not a reference behaviour)", "gn_iterations_per_level_finest_first": sched, "frame_pairs_per_s": B * gn_steps / tg,
                    "ms_per_step": 1e3 * tg / gn_steps, "steps": gn_steps,
-                   "accuracy_note": "rendered sequence with exact ground truth: ATE 0.25 mm against 1.06 mm for the metric's V1 at 10 "
+                   "accuracy_note": "rendered sequence with exact ground truth: ATE 0.21 mm against 1.06 mm for the metric's V1 at 10 "
                                     "iterations per level (DESIGN.md section 6)"}
         for a in al.parts:
             a.variant, a.max_iterations = _cabi.VARIANT_V1, args.iterations
+            a.ctx.set_level_iterations(None)
 
     if rank == 0:
         P0 = W * H
@@ -335,7 +340,8 @@ def main():
             "data": "synthetic",
             "config": {"workload": "synthetic %dx%d RGB-D stream, %d-level pyramid, %d GN iterations/level, "
                                    "%d frame pairs per GPU per step (pyramid + Sobel + valid-point-list build and device-side GN solve "
-                                   "inside the timed region), weighting=%s, variant=%s" % (W, H, L, args.iterations, B, args.weighting, args.variant),
+                                   "inside the timed region), weighting=%s, variant=%s%s" % (W, H, L, args.iterations, B, args.weighting, args.variant,
+                                                                                          (", iterations per level (finest first) " + args.level_iterations) if args.level_iterations else ""),
                        "batch_pairs_per_gpu": B, "streams_per_gpu": args.streams, "distinct_frames": int(min(n_distinct, n_frames)),
                        "gn_iterations_per_pair": iters_total / B,
                        "gn_iterations_per_s": world * iters_total * args.steps / elapsed,

@@ -42,6 +42,7 @@ struct SolveKey {
     double tolerance, weight_param, inv_sigma;
     const void* trace;
     const void* stream;
+    int level_iters[DVO_MAX_LEVELS];    // iterations per level (dvo_set_level_iterations), or max_iterations at every level
 };
 
 struct dvo_ctx {
@@ -52,6 +53,9 @@ struct dvo_ctx {
     size_t slot_stride = 0;
     uint8_t* d_slots = nullptr;
     std::vector<SlotInfo> slots;
+    // optional per-level iteration schedule (dvo_set_level_iterations)
+    bool level_iters_set = false;
+    int level_iters[DVO_MAX_LEVELS] = {0};
     // camera
     bool have_camera = false;
     float fx = 0, fy = 0, cx = 0, cy = 0, skew = 0;
@@ -1053,7 +1057,7 @@ int dvo_residuals_jacobian(dvo_ctx* ctx, int level, int prev_slot, int cur_slot,
 // Enqueues (or, under stream capture, records) the launch sequence of one batched coarse-to-fine solve.
 static int record_solve(dvo_ctx* ctx, const SolveKey& k, const float* d_init)
 {
-    const int n_pairs = k.n_pairs, w = k.w, h = k.h, levels = k.levels, max_iterations = k.max_iterations;
+    const int n_pairs = k.n_pairs, w = k.w, h = k.h, levels = k.levels;
     const int variant = k.variant, weight_mode = k.weight_mode, max_increased_steps_allowed = k.max_increased;
     const double tolerance = k.tolerance, weight_param = k.weight_param;
     int rc;
@@ -1065,7 +1069,7 @@ static int record_solve(dvo_ctx* ctx, const SolveKey& k, const float* d_init)
     // doing every iteration of those levels (k_gn_small); the finer levels take one reduction launch + one control launch
     // per iteration.
     int level = levels - 1;
-    if (variant != DVO_VARIANT_V3 && max_iterations > 0) {
+    if (variant != DVO_VARIANT_V3) {
         DvoLevelGeom g[DVO_MAX_LEVELS];
         level_geometry(w, h, levels, g, nullptr);
         DvoSmallParams sp;
@@ -1076,6 +1080,7 @@ static int record_solve(dvo_ctx* ctx, const SolveKey& k, const float* d_init)
         const int max_pix = (n_pairs <= 16) ? (ctx->knobs.small_max_pix < 4800 ? ctx->knobs.small_max_pix : 4800) : ctx->knobs.small_max_pix;
         while (level - n >= 0 && n < DVO_SMALL_LEVELS && g[level - n].npix <= max_pix) {
             sp.level_id[n] = level - n;
+            sp.level_iters[n] = k.level_iters[level - n];
             sp.g[n] = g[level - n];
             sp.cam[n] = level_camera(ctx, level - n);
             ++n;
@@ -1089,7 +1094,6 @@ static int record_solve(dvo_ctx* ctx, const SolveKey& k, const float* d_init)
             sp.n_levels = n;
             sp.depth_scale = ctx->depth_scale;
             sp.n_pairs = n_pairs;
-            sp.max_iterations = max_iterations;
             sp.state = ctx->d_state;
             sp.T = ctx->d_T;
             sp.active = ctx->d_active;
@@ -1148,7 +1152,7 @@ static int record_solve(dvo_ctx* ctx, const SolveKey& k, const float* d_init)
         sp.irls_done = nullptr;
         sp.phase = 0;
         HIP_TRY(ctx, dvo_launch_level_begin(ctx->d_state, ctx->d_active, ctx->d_wparam, n_pairs, weight_mode, lambda0, ctx->stream));
-        for (int it = 0; it < max_iterations; ++it) {
+        for (int it = 0; it < k.level_iters[level]; ++it) {
             if (weight_mode == DVO_WEIGHT_STUDENT_T || weight_mode == DVO_WEIGHT_STUDENT_T_MEAN) {
                 // IRLS scale passes (weighter/t_weighter.py:24-32): the first keeps the residuals of this pose, the later ones sum
                 // them again under the new lambda
@@ -1240,6 +1244,7 @@ int dvo_solve_batch_enqueue(dvo_ctx* ctx, int n_pairs, const int* prev_slot, con
     key.trace = ctx->d_trace; key.trace_cap = ctx->trace_cap; key.stream = ctx->stream;
     key.inv_sigma = (ctx->prior_sigma > 0.0) ? 1.0 / ctx->prior_sigma : 0.0;
     key.has_last = ctx->prior_has_last ? 1 : 0;
+    for (int l = 0; l < levels && l < DVO_MAX_LEVELS; ++l) key.level_iters[l] = ctx->level_iters_set ? ctx->level_iters[l] : max_iterations;
     const bool use_graph = ctx->graphs_enabled && !ctx->profiling;
     if (use_graph) {
         for (auto& g : ctx->graphs)
@@ -1323,6 +1328,18 @@ int dvo_set_prior(dvo_ctx* ctx, double sigma, const double* last_qt, int n_pairs
         HIP_TRY(ctx, hipMemcpyAsync(ctx->d_prior, ctx->h_prior, (size_t)n_pairs * 7 * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
         ctx->prior_has_last = true;
     }
+    return DVO_OK;
+}
+
+int dvo_set_level_iterations(dvo_ctx* ctx, const int* iters, int n_levels)
+{
+    if (!ctx) return DVO_ERR_INVALID_ARG;
+    if (!iters || n_levels <= 0) { ctx->level_iters_set = false; return DVO_OK; }
+    if (n_levels > DVO_MAX_LEVELS) return fail(ctx, DVO_ERR_INVALID_ARG, "n_levels %d exceeds %d", n_levels, DVO_MAX_LEVELS);
+    for (int l = 0; l < n_levels; ++l)
+        if (iters[l] < 0) return fail(ctx, DVO_ERR_INVALID_ARG, "iterations of level %d negative", l);
+    for (int l = 0; l < DVO_MAX_LEVELS; ++l) ctx->level_iters[l] = (l < n_levels) ? iters[l] : iters[n_levels - 1];
+    ctx->level_iters_set = true;
     return DVO_OK;
 }
 

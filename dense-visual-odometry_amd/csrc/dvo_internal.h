@@ -135,7 +135,7 @@ struct DvoSmallParams {
     DvoLevelCam cam[DVO_SMALL_LEVELS];
     double depth_scale;
     int n_pairs;
-    int max_iterations;
+    int level_iters[DVO_SMALL_LEVELS];   // iterations of level_id[k]
     DvoPairState* state;         // [n_pairs]
     float* T;                    // [n_pairs][12]
     int* active;                 // [n_pairs]

@@ -1884,7 +1884,7 @@ __global__ __launch_bounds__(DVO_SMALL_MAX_THREADS) void k_gn_small(const DvoSma
             if (WMODE == 2) wpar_sh = (st.lambda > 0.0) ? st.lambda : DVO_FLT_MAX;        // no scale yet: w = 1
         }
         __syncthreads();
-        for (int it = 0; it < p.max_iterations; ++it) {
+        for (int it = 0; it < p.level_iters[li]; ++it) {
             if (active_sh == 0) break;                    // workgroup-uniform: written before the barrier that ended the last iteration
             // the pose is workgroup-uniform: keep it in SGPRs like k_reduce does (LDS loads land in VGPRs)
             float T[12];

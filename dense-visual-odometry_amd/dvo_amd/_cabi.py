@@ -73,6 +73,7 @@ SIGNATURES = {
     "dvo_solve_batch_fetch": (C.c_int, [_ctx, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "dvo_debug_divide": (C.c_int, [_ctx, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]),
     "dvo_set_prior": (C.c_int, [_ctx, C.c_double, C.c_void_p, C.c_int]),
+    "dvo_set_level_iterations": (C.c_int, [_ctx, C.c_void_p, C.c_int]),
     "dvo_comm_unique_id": (C.c_int, [C.c_void_p]),
     "dvo_comm_create": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_void_p)]),
     "dvo_allgather_poses": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
@@ -384,6 +385,15 @@ class HipContext:
         err = np.empty(n, dtype=np.float64)
         self._check(self._lib.dvo_solve_batch_fetch(self._h, n, _ptr(T), _ptr(xi), _ptr(iters), _ptr(err)))
         return dict(T=T, xi=xi, iters=iters, err=err)
+
+    def set_level_iterations(self, iters) -> None:
+        """Per-level iteration schedule (level 0 = finest) for the following solve_batch calls; None restores one max_iterations
+        for every level (the reference's behaviour)."""
+        if iters is None:
+            self._check(self._lib.dvo_set_level_iterations(self._h, None, 0))
+            return
+        a = np.ascontiguousarray(np.asarray(iters, dtype=np.int32).reshape(-1))
+        self._check(self._lib.dvo_set_level_iterations(self._h, _ptr(a), int(a.shape[0])))
 
     def set_prior(self, sigma: Optional[float], last_qt: Optional[np.ndarray] = None):
         """Motion prior for the following solve_batch calls (sigma None/<=0: off). last_qt: (n,7) qw qx qy qz tx ty tz."""

@@ -26,7 +26,7 @@ class BatchAligner:
     def __init__(self, K: np.ndarray, depth_scale: float, width: int = 640, height: int = 480, levels: int = 4,
                  max_pairs: int = 64, device: int = 0, max_iterations: int = 10, tolerance: float = 1e-6,
                  max_increased_steps_allowed: int = 0, weighting: str = "none", huber_k: float = 1.345,
-                 approximate_image2_gradient: bool = False, reference_variant: str = "cpu"):
+                 approximate_image2_gradient: bool = False, reference_variant: str = "cpu", level_iterations=None):
         if weighting not in _WEIGHTS:
             raise ValueError("weighting must be one of {}".format(sorted(_WEIGHTS)))
         self.width, self.height, self.levels, self.max_pairs = width, height, levels, max_pairs
@@ -44,6 +44,7 @@ class BatchAligner:
                                     n_slots=max_pairs + 1, max_pairs=max_pairs)
         K = np.asarray(K, dtype=np.float32)
         self.ctx.set_camera(K[0, 0], K[1, 1], K[0, 2], K[1, 2], K[0, 1], depth_scale)
+        self.ctx.set_level_iterations(level_iterations)      # build-defined schedule (level 0 = finest); None = max_iterations everywhere
         self._slots = np.arange(max_pairs + 1, dtype=np.int32)
 
     def close(self):

@@ -73,7 +73,7 @@ class RobustDVOHIP:
                  max_iterations: int = 100, approximate_image2_gradient: bool = False,
                  height: int = 480, width: int = 640, device: int = 0, solver: str = "host",
                  weighting: Optional[str] = None, huber_k: float = 1.345, max_distance: float = 5.0,
-                 mutate_depth: bool = True, reference_variant: str = "cpu"):
+                 mutate_depth: bool = True, reference_variant: str = "cpu", level_iterations=None):
         if levels < 1:
             raise ValueError("Expected 'levels' to be >= 1, got '{}' instead".format(levels))
         if solver not in ("host", "device"):
@@ -89,6 +89,10 @@ class RobustDVOHIP:
         self._sigma = sigma                 # motion prior (base_robust_dvo.py:69-71); None = off (reference default)
         self._tolerance = tolerance
         self._max_iter = max_iterations
+        # build-defined: iterations per level (0 = finest) instead of one max_iterations for all; None = the reference's behaviour
+        self._level_iters = None if level_iterations is None else [int(v) for v in level_iterations]
+        if self._level_iters is not None and (len(self._level_iters) == 0 or min(self._level_iters) < 0):
+            raise ValueError("level_iterations must be a non-empty sequence of non-negative integers")
         self._approximate_image2_gradients = approximate_image2_gradient
         # which of the reference's behaviours to reproduce: "cpu" = RobustDVOCPU (V1, or V2 with
         # approximate_image2_gradient), "cuda" = its numba.cuda kernel (V3: central-difference gradient of I1,
@@ -113,6 +117,7 @@ class RobustDVOHIP:
         self._mutate_depth = mutate_depth
 
         self._ctx = _cabi.HipContext(device=device, max_w=width, max_h=height, max_levels=levels, n_slots=2, max_pairs=1)
+        self._ctx.set_level_iterations(self._level_iters)
         K = camera_model.intrinsics
         self._ctx.set_camera(K[0, 0], K[1, 1], K[0, 2], K[1, 2], K[0, 1], camera_model.depth_scale)
         self._prev_slot, self._cur_slot = 0, 1
@@ -312,7 +317,8 @@ class RobustDVOHIP:
             err_increased_count = 0
             self._t_lambda = 1.0 / 25.0                     # "student_t": every level starts from initial_sigma = 5
             self._setup(level=level)
-            for i in range(self._max_iter):
+            n_iter = self._max_iter if self._level_iters is None else self._level_iters[min(level, len(self._level_iters) - 1)]
+            for i in range(n_iter):
                 H, b, err, n = self.compute_normal_equations(estimate=estimate, level=level)
                 self.last_iterations += 1
                 if old is not None:                                               # :190-194
@@ -341,9 +347,9 @@ class RobustDVOHIP:
                 if err_increased_count > self._max_increased_steps_allowed:
                     logger.info("Error increased on iteration '{}' (error: {:.4f})".format(i, err))
                     break
-                if i == (self._max_iter - 1):
+                if i == (n_iter - 1):
                     logger.warning("Exceeded maximum number of iterations '{}' (error: {:.4f})".format(
-                        self._max_iter, err))
+                        n_iter, err))
             self._cleanup()
         return estimate
 

@@ -213,6 +213,12 @@ int dvo_solve_batch_fetch(dvo_ctx* ctx, int n_pairs, float* T_out, double* xi_ou
  * consecutive pairs of a sequence, so with it a sequence is processed pair after pair (SURVEY 8e "when not"). */
 int dvo_set_prior(dvo_ctx* ctx, double sigma, const double* last_qt, int n_pairs);
 
+/* Optional iteration schedule for subsequent dvo_solve_batch calls: level l (0 = finest) runs at most iters[l] Gauss-Newton
+ * iterations instead of the call's max_iterations (0 skips the level; levels beyond n_levels take iters[n_levels - 1]).
+ * iters == NULL or n_levels <= 0 restores the reference's behaviour, one max_iterations for every level
+ * (base_robust_dvo.py:161).  Build-defined: meant for DVO_VARIANT_GN, which converges in 1-3 iterations per level. */
+int dvo_set_level_iterations(dvo_ctx* ctx, const int* iters, int n_levels);
+
 /* Per-iteration trace of dvo_solve_batch (tests / debugging): enable with the number of iterations to keep
  * per pair (0 disables).  Each record is DVO_TRACE_STRIDE doubles: the normal-equation record [0..31], the
  * solved increment xi [32..37] and the 3x4 pose the iteration was evaluated at [38..49]. */

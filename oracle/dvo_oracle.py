@@ -25,7 +25,7 @@ from __future__ import annotations
 
 import math
 from dataclasses import dataclass
-from typing import List, Optional, Tuple
+from typing import Sequence, List, Optional, Tuple
 
 import numpy as np
 import scipy.linalg
@@ -612,8 +612,10 @@ def gauss_newton(gray_prev, depth_prev, gray_cur, K, depth_scale, levels: int, m
                  tolerance: float = 1e-6, max_increased_steps_allowed: int = 0, use_weighter: bool = False,
                  variant: str = VARIANT_V1, accumulate: str = "fp64", weighting: Optional[str] = None,
                  huber_k: float = 1.345, init: Optional[Pose] = None, record: Optional[list] = None,
-                 sigma: Optional[float] = None, last_transform: Optional[Pose] = None) -> Pose:
-    """BaseRobustDVO._step, base_robust_dvo.py:137-236.  `sigma` / `last_transform`: the motion prior of
+                 sigma: Optional[float] = None, last_transform: Optional[Pose] = None,
+                 level_iterations: Optional[Sequence[int]] = None) -> Pose:
+    """BaseRobustDVO._step, base_robust_dvo.py:137-236.  `level_iterations` (build-defined, dvo_set_level_iterations): iterations per
+    level instead of one max_iterations for all.    `sigma` / `last_transform`: the motion prior of
     :69-71, :154, :190-194, :217-218 (`last_transform` = self._last_estimated_transform)."""
     gp = build_pyramid(gray_prev, levels)
     dp = build_pyramid(depth_prev, levels)
@@ -630,7 +632,7 @@ def gauss_newton(gray_prev, depth_prev, gray_cur, K, depth_scale, levels: int, m
         old = None
         if sigma is not None and last_transform is not None:
             old = Pose(np.array(last_transform.quat), np.array(last_transform.tvec))      # :154
-        for i in range(max_iterations):
+        for i in range(max_iterations if level_iterations is None else int(level_iterations[min(level, len(level_iterations) - 1)])):
             T = estimate.matrix()
             r, J, _, _ = residuals_and_jacobian(lv, T, variant)
             n = r.shape[0]

@@ -431,6 +431,38 @@ def test_variant_gn_batched_with_weights_vs_oracle(vga_stream):
             np.testing.assert_allclose(res["xi"][k], est.log(), rtol=0, atol=5e-6, err_msg=weighting)
 
 
+def test_level_iteration_schedule_vs_oracle(vga_stream):
+    """dvo_set_level_iterations: per-level iteration counts (finest first, 0 skips a level) on the batched device solve and on
+    the host loop of the drop-in class, against the oracle's loop with the same schedule; clearing it restores max_iterations."""
+    import dvo_amd
+    from dvo_amd.batch import BatchAligner
+    st = vga_stream
+    for variant, kw in (("gn", dict(reference_variant="gn")), ("v1", dict())):
+        for sched in ([1, 2, 3, 2], [0, 2, 1, 3]):
+            al = BatchAligner(st["K"], st["depth_scale"], 640, 480, 4, max_pairs=8, max_iterations=7, level_iterations=sched, **kw)
+            res = al.align_host(st["gray"][:3], st["depth"][:3])
+            for k in range(2):
+                est = O.gauss_newton(st["gray"][k], st["depth"][k], st["gray"][k + 1], st["K"], st["depth_scale"], levels=4,
+                                     max_iterations=7, variant=variant, level_iterations=sched)
+                np.testing.assert_allclose(res["xi"][k], est.log(), rtol=0, atol=5e-6, err_msg=str((variant, sched)))
+                assert res["iters"][k] <= sum(sched)
+            al.ctx.set_level_iterations(None)                                     # back to max_iterations = 7 at every level
+            res7 = al.align_host(st["gray"][:3], st["depth"][:3])
+            al.close()
+            est7 = O.gauss_newton(st["gray"][0], st["depth"][0], st["gray"][1], st["K"], st["depth_scale"], levels=4,
+                                  max_iterations=7, variant=variant)
+            np.testing.assert_allclose(res7["xi"][0], est7.log(), rtol=0, atol=5e-6)
+    cam = dvo_amd.RGBDCameraModel(st["K"], st["depth_scale"])
+    est = O.gauss_newton(st["gray"][0], st["depth"][0], st["gray"][1], st["K"], st["depth_scale"], levels=4, max_iterations=9,
+                         variant="gn", level_iterations=[1, 2, 2, 3])
+    for solver in ("host", "device"):
+        dvo = dvo_amd.get_dvo("robust-dvo", cam, dvo_amd.Se3.identity(), levels=4, max_iterations=9, solver=solver,
+                              reference_variant="gn", level_iterations=[1, 2, 2, 3])
+        dvo.step_gray(st["gray"][0], st["depth"][0])
+        tf = dvo.step_gray(st["gray"][1], st["depth"][1])
+        np.testing.assert_allclose(tf.log().reshape(6), est.log(), rtol=0, atol=5e-6)
+
+
 def test_persistent_small_level_kernel_vs_per_iteration_launches(vga_stream, monkeypatch):
     """The coarse levels (<= 160x120) run in one persistent launch per batch (k_gn_small), a workgroup per pair; with
     DVO_SMALL_MAX_PIX=0 every level takes the per-iteration launches (k_reduce + k_solve).  Same per-record arithmetic,

@@ -39,6 +39,7 @@ def parse_args():
     ap.add_argument("--variant", default="v1", choices=["v1", "v2", "v3", "gn"],
                     help="v1 / v2 / v3: the reference's behaviours (CPU default, approximate_image2_gradient, numba.cuda kernel); "
                          "gn: the build's true Gauss-Newton mode (DVO_VARIANT_GN), which needs ~3 iterations per level")
+    ap.add_argument("--level-iterations", type=str, default=None, help="comma-separated iterations per level, finest first (overrides --iterations)")
     ap.add_argument("--window", type=int, default=128, help="frame pairs per batched upload + solve")
     ap.add_argument("--streams", type=int, default=2, help="HIP streams (slices of a window) per GPU")
     ap.add_argument("--decoders", type=int, default=8, help="PNG decoder threads (TUM mode)")
@@ -114,7 +115,8 @@ def main():
         return StreamedAligner(K, scale, w, h, args.levels, max_pairs=window, n_streams=args.streams, device=local_rank,
                                max_iterations=args.iterations, weighting=args.weighting,
                                approximate_image2_gradient=(args.variant == "v2"),
-                               reference_variant={"v3": "cuda", "gn": "gn"}.get(args.variant, "cpu"))
+                               reference_variant={"v3": "cuda", "gn": "gn"}.get(args.variant, "cpu"),
+                               level_iterations=([int(v) for v in args.level_iterations.split(",")] if args.level_iterations else None))
 
     res = sequence.align_shard(make_aligner, source, n_total, rank if use_dist else 0, world if use_dist else 1, args.window,
                                colour, alloc=_cabi.pinned_array, workers=args.decoders, streams=args.streams)
@@ -137,7 +139,7 @@ def main():
              "seconds_decode_thread": decode_s,
              "frame_pairs_per_s_including_decode_and_upload": (n_local / res["seconds"]) * world if res["seconds"] > 0 else None,
              "gn_iterations_mean": float(np.mean(iters)) if len(iters) else 0.0, "input": "bgr" if colour else "gray",
-             "variant": args.variant, "max_iterations_per_level": args.iterations}
+             "variant": args.variant, "max_iterations_per_level": args.iterations, "level_iterations": args.level_iterations}
     report, traj = sequence.build_report(kind, T_rel, gt[0] if gt is not None else None, gt, stamps, extra)
     sequence.write_report(args.out, report, traj)
     print(json.dumps({k: v for k, v in report.items() if not isinstance(v, list)}))
