@@ -463,36 +463,61 @@ __device__ __forceinline__ int wave_sum_i(int v)
     return v;
 }
 
+// What one wave holds of one segment between its loads and its scatter.
+struct ListSegData {
+    unsigned dw[8];      // 16 depths, two per word
+    unsigned gw[4];      // 16 intensities
+    int l, sl;           // level and segment within the level
+    bool live;           // the segment exists
+};
+
 template <bool SCATTER>
-__global__ __launch_bounds__(DVO_BLOCK) void k_list_build(const DvoBatchIngestParams p, int segs_per_frame, int seg_begin,
-                                                          int seg_end)
+__device__ __forceinline__ void list_seg_load(const DvoBatchIngestParams& p, const uint8_t* slot, int seg, int seg_end, int lane,
+                                              ListSegData& d)
 {
-    __shared__ DvoPointRec stage[SCATTER ? DVO_BLOCK / 64 : 1][SCATTER ? DVO_LIST_SEG / 2 : 1];    // half a segment per wave: 16 KB per workgroup
-    const int f = blockIdx.z;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int seg = seg_begin + (int)blockIdx.x * (DVO_BLOCK / 64) + wave;
-    if (seg >= seg_end) return;                                            // wave-uniform
-    int sl;
-    const int l = list_level_of_segment(p, seg, sl);
-    const DvoLevelGeom& g = p.g[l];
-    uint8_t* slot = p.slots + (size_t)p.slot_ids[f] * p.slot_stride;
+    d.live = seg < seg_end;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) d.dw[k] = 0u;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) d.gw[k] = 0u;
+    d.l = 0; d.sl = 0;
+    if (!d.live) return;                                                   // wave-uniform
+    d.l = list_level_of_segment(p, seg, d.sl);
+    const DvoLevelGeom& g = p.g[d.l];
     const uint16_t* depth = reinterpret_cast<const uint16_t*>(slot + g.off_depth);
-    const int idx0 = sl * DVO_LIST_SEG + lane * 16;
-    unsigned dw[8];                                                        // 16 depths, two per word
+    const uint8_t* gray = slot + g.off_gray;
+    const int idx0 = d.sl * DVO_LIST_SEG + lane * 16;
     if (idx0 + 16 <= g.npix) {
         const uint4 a = *reinterpret_cast<const uint4*>(depth + idx0), b = *reinterpret_cast<const uint4*>(depth + idx0 + 8);
-        dw[0] = a.x; dw[1] = a.y; dw[2] = a.z; dw[3] = a.w; dw[4] = b.x; dw[5] = b.y; dw[6] = b.z; dw[7] = b.w;
+        d.dw[0] = a.x; d.dw[1] = a.y; d.dw[2] = a.z; d.dw[3] = a.w; d.dw[4] = b.x; d.dw[5] = b.y; d.dw[6] = b.z; d.dw[7] = b.w;
+        if (SCATTER) {
+            const uint4 c = *reinterpret_cast<const uint4*>(gray + idx0);
+            d.gw[0] = c.x; d.gw[1] = c.y; d.gw[2] = c.z; d.gw[3] = c.w;
+        }
     } else {
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
             const int i0 = idx0 + 2 * k, i1 = i0 + 1;
-            dw[k] = ((i0 < g.npix) ? (unsigned)depth[i0] : 0u) | (((i1 < g.npix) ? (unsigned)depth[i1] : 0u) << 16);
+            d.dw[k] = ((i0 < g.npix) ? (unsigned)depth[i0] : 0u) | (((i1 < g.npix) ? (unsigned)depth[i1] : 0u) << 16);
+        }
+        if (SCATTER) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+#pragma unroll
+                for (int b = 0; b < 4; ++b) if (idx0 + 4 * k + b < g.npix) d.gw[k] |= (unsigned)gray[idx0 + 4 * k + b] << (8 * b);
         }
     }
+}
+
+template <bool SCATTER>
+__device__ __forceinline__ void list_seg_emit(const DvoBatchIngestParams& p, uint8_t* slot, int* segc, int lane, const ListSegData& d,
+                                              DvoPointRec* st)
+{
+    if (!d.live) return;                                                   // wave-uniform
+    const DvoLevelGeom& g = p.g[d.l];
     int cnt = 0;
 #pragma unroll
-    for (int k = 0; k < 8; ++k) cnt += ((dw[k] & 0xffffu) != 0u) + ((dw[k] >> 16) != 0u);
-    int* segc = p.seg_counts + (size_t)f * segs_per_frame + seg;
+    for (int k = 0; k < 8; ++k) cnt += ((d.dw[k] & 0xffffu) != 0u) + ((d.dw[k] >> 16) != 0u);
     if (!SCATTER) {
         const int tot = wave_sum_i(cnt);
         if (lane == 0) *segc = tot;
@@ -506,22 +531,9 @@ __global__ __launch_bounds__(DVO_BLOCK) void k_list_build(const DvoBatchIngestPa
         if (lane >= off) incl += v;
     }
     const int total = __shfl(incl, 63, 64);
-    int pos = incl - cnt;
-    const uint8_t* gray = slot + g.off_gray;
-    unsigned gw[4];
-    if (idx0 + 16 <= g.npix) {
-        const uint4 a = *reinterpret_cast<const uint4*>(gray + idx0);
-        gw[0] = a.x; gw[1] = a.y; gw[2] = a.z; gw[3] = a.w;
-    } else {
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            gw[k] = 0u;
-#pragma unroll
-            for (int b = 0; b < 4; ++b) if (idx0 + 4 * k + b < g.npix) gw[k] |= (unsigned)gray[idx0 + 4 * k + b] << (8 * b);
-        }
-    }
+    const int pos = incl - cnt;
+    const int idx0 = d.sl * DVO_LIST_SEG + lane * 16;
     int y = idx0 / g.w, x = idx0 - y * g.w;
-    DvoPointRec* st = stage[wave];
     DvoPointRec* list = reinterpret_cast<DvoPointRec*>(slot + g.off_list) + *segc;     // exclusive offset (k_list_scan)
     // The segment is compacted in two rounds through a half-size stage (lanes 0..31, then lanes 32..63): 4 KB of LDS per wave lets
     // 8 workgroups share a CU instead of 5 (the scatter is bound by bytes in flight: 197 -> 181 us per 257 VGA frames).
@@ -532,11 +544,11 @@ __global__ __launch_bounds__(DVO_BLOCK) void k_list_build(const DvoBatchIngestPa
             int q = pos - base;
 #pragma unroll
             for (int k = 0; k < 16; ++k) {
-                const unsigned d = (dw[k >> 1] >> ((k & 1) * 16)) & 0xffffu;
-                if (d != 0u) {
+                const unsigned dd = (d.dw[k >> 1] >> ((k & 1) * 16)) & 0xffffu;
+                if (dd != 0u) {
                     DvoPointRec rec;
-                    rec.z = (float)((double)d * p.depth_scale);             // camera_model.py:200-201
-                    rec.pix = (unsigned)x | ((unsigned)y << 12) | (((gw[k >> 2] >> ((k & 3) * 8)) & 0xffu) << 24);
+                    rec.z = (float)((double)dd * p.depth_scale);            // camera_model.py:200-201
+                    rec.pix = (unsigned)x | ((unsigned)y << 12) | (((d.gw[k >> 2] >> ((k & 3) * 8)) & 0xffu) << 24);
                     st[q++] = rec;
                 }
                 if (++x == g.w) { x = 0; ++y; }
@@ -550,7 +562,7 @@ __global__ __launch_bounds__(DVO_BLOCK) void k_list_build(const DvoBatchIngestPa
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
-    if (sl == g.nseg - 1) {
+    if (d.sl == g.nseg - 1) {
         // tail padding: 256 records with z = NaN behind the last real one (inside DVO_LIST_SLACK).  A wave of k_reduce reads whole
         // 256-record groups; a NaN depth makes every warped coordinate NaN, which fails the in-bounds test like any other invalid
         // point — so the reduction needs no per-record `index < count` test (2 instructions per point).
@@ -559,6 +571,29 @@ __global__ __launch_bounds__(DVO_BLOCK) void k_list_build(const DvoBatchIngestPa
         pad.pix = 0u;
         for (int i = lane; i < 64 * DVO_PX_PER_THREAD; i += 64) list[total + i] = pad;
     }
+}
+
+// One wave takes DVO_LIST_SEGS_PER_WAVE consecutive segments, all loads (depth and intensity) issued before the first compaction.
+// Measured per 257 VGA frames: 1 / 2 / 4 segments per wave 176 / 188 / 210 us — more independent waves beat longer ones.
+#ifndef DVO_LIST_SEGS_PER_WAVE
+#define DVO_LIST_SEGS_PER_WAVE 1
+#endif
+template <bool SCATTER>
+__global__ __launch_bounds__(DVO_BLOCK) void k_list_build(const DvoBatchIngestParams p, int segs_per_frame, int seg_begin,
+                                                          int seg_end)
+{
+    __shared__ DvoPointRec stage[SCATTER ? DVO_BLOCK / 64 : 1][SCATTER ? DVO_LIST_SEG / 2 : 1];    // half a segment per wave: 16 KB per workgroup
+    const int f = blockIdx.z;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int seg0 = seg_begin + ((int)blockIdx.x * (DVO_BLOCK / 64) + wave) * DVO_LIST_SEGS_PER_WAVE;
+    if (seg0 >= seg_end) return;                                           // wave-uniform
+    uint8_t* slot = p.slots + (size_t)p.slot_ids[f] * p.slot_stride;
+    ListSegData d[DVO_LIST_SEGS_PER_WAVE];
+#pragma unroll
+    for (int k = 0; k < DVO_LIST_SEGS_PER_WAVE; ++k) list_seg_load<SCATTER>(p, slot, seg0 + k, seg_end, lane, d[k]);
+#pragma unroll
+    for (int k = 0; k < DVO_LIST_SEGS_PER_WAVE; ++k)
+        list_seg_emit<SCATTER>(p, slot, p.seg_counts + (size_t)f * segs_per_frame + seg0 + k, lane, d[k], stage[wave]);
 }
 
 // exclusive scan of the per-segment counts of one (frame, level); total -> list_count[slot][level]
@@ -622,7 +657,7 @@ hipError_t dvo_launch_batch_ingest(const DvoBatchIngestParams& p, hipStream_t s)
                 hipLaunchKernelGGL(k_batch_copy_level0, cg, dim3(DVO_BLOCK), 0, s, p);
             }
             hipLaunchKernelGGL(k_batch_sobel_pack, grid, dim3(DVO_BLOCK), 0, s, p, l);
-            const unsigned cb = (unsigned)((g.nseg + DVO_BLOCK / 64 - 1) / (DVO_BLOCK / 64));
+            const unsigned cb = (unsigned)((g.nseg + (DVO_BLOCK / 64) * DVO_LIST_SEGS_PER_WAVE - 1) / ((DVO_BLOCK / 64) * DVO_LIST_SEGS_PER_WAVE));
             hipLaunchKernelGGL(k_list_build<false>, dim3(cb, 1, nf), dim3(DVO_BLOCK), 0, s, p, segs, seg_base, seg_base + g.nseg);
             if (l + 1 < p.levels) {
                 const DvoLevelGeom& gn = p.g[l + 1];
@@ -634,7 +669,7 @@ hipError_t dvo_launch_batch_ingest(const DvoBatchIngestParams& p, hipStream_t s)
         seg_base += g.nseg;
     }
     hipLaunchKernelGGL(k_list_scan, dim3((unsigned)p.levels, nf), dim3(DVO_BLOCK), 0, s, p, segs);
-    const unsigned lb = (unsigned)((segs + DVO_BLOCK / 64 - 1) / (DVO_BLOCK / 64));
+    const unsigned lb = (unsigned)((segs + (DVO_BLOCK / 64) * DVO_LIST_SEGS_PER_WAVE - 1) / ((DVO_BLOCK / 64) * DVO_LIST_SEGS_PER_WAVE));
     hipLaunchKernelGGL(k_list_build<true>, dim3(lb, 1, nf), dim3(DVO_BLOCK), 0, s, p, segs, 0, segs);
     return hipGetLastError();
 }
