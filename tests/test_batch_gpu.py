@@ -463,6 +463,21 @@ def test_level_iteration_schedule_vs_oracle(vga_stream):
         np.testing.assert_allclose(tf.log().reshape(6), est.log(), rtol=0, atol=5e-6)
 
 
+def test_zero_iterations_return_the_initial_pose(vga_stream):
+    """max_iterations = 0 (and an all-zero schedule): the reference's level loop does not run (base_robust_dvo.py:161), the
+    estimate is the initial guess and no iteration is counted — for small and large batches (persistent kernel or not)."""
+    from dvo_amd.batch import BatchAligner
+    st = vga_stream
+    for n_pairs in (2, 8):
+        for kw in (dict(max_iterations=0), dict(max_iterations=5, level_iterations=[0, 0, 0, 0])):
+            al = BatchAligner(st["K"], st["depth_scale"], 640, 480, 4, max_pairs=8, **kw)
+            res = al.align_host(st["gray"][:n_pairs + 1], st["depth"][:n_pairs + 1])
+            al.close()
+            assert np.all(res["iters"] == 0)
+            np.testing.assert_allclose(res["xi"], 0.0, atol=1e-12)
+            np.testing.assert_allclose(res["T"], np.tile(np.eye(4, dtype=np.float32)[:3], (n_pairs, 1, 1)), atol=1e-7)
+
+
 def test_persistent_small_level_kernel_vs_per_iteration_launches(vga_stream, monkeypatch):
     """The coarse levels (<= 160x120) run in one persistent launch per batch (k_gn_small), a workgroup per pair; with
     DVO_SMALL_MAX_PIX=0 every level takes the per-iteration launches (k_reduce + k_solve).  Same per-record arithmetic,
