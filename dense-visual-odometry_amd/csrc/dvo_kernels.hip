@@ -677,6 +677,22 @@ hipError_t dvo_launch_batch_ingest(const DvoBatchIngestParams& p, hipStream_t s)
 // ================================================================================================
 // the per-pixel pipeline shared by K3 and K5
 // ================================================================================================
+// Valid-point records are read once per launch: a non-temporal load (`nt`) keeps them from displacing the texel lines and the
+// coarser levels' data in the L2 / Infinity Cache.  DVO_NT_RECORDS(TAG) says for which kernels (TAG != 0: level 0).
+#ifndef DVO_NT_MODE
+#define DVO_NT_MODE 1               // 0: never, 1: level 0 (kernel tags 1, 2), 2: every level
+#endif
+#define DVO_NT_RECORDS(TAG) (DVO_NT_MODE == 2 || (DVO_NT_MODE == 1 && (TAG) != 0))
+template <bool NT>
+__device__ __forceinline__ uint2 dvo_rec_load(const uint2* p)
+{
+    if (NT) {
+        const unsigned long long v = __builtin_nontemporal_load(reinterpret_cast<const unsigned long long*>(p));
+        return make_uint2((unsigned)v, (unsigned)(v >> 32));
+    }
+    return *p;
+}
+
 struct PixelOut {
     float r;
     float J[6];
@@ -1041,7 +1057,7 @@ __global__ __launch_bounds__(DVO_BLOCK, (VARIANT == 2) ? 2 : DVO_REDUCE_WAVES_PE
     for (int j = 0; j < DVO_PX_PER_THREAD; ++j) rn[j] = make_uint2(0u, 0u);
     if (g_lo < g_hi && rec0 < count) {
 #pragma unroll
-        for (int j = 0; j < DVO_PX_PER_THREAD; ++j) rn[j] = *reinterpret_cast<const uint2*>(list + rec0 + j * 64 + lane_);
+        for (int j = 0; j < DVO_PX_PER_THREAD; ++j) rn[j] = dvo_rec_load<DVO_NT_RECORDS(TAG)>(reinterpret_cast<const uint2*>(list + rec0 + j * 64 + lane_));
     }
     for (int grp = g_lo; grp < g_hi; ++grp) {
         const int seg = grp * DVO_PX_PER_BLOCK + wave_off;
@@ -1053,7 +1069,7 @@ __global__ __launch_bounds__(DVO_BLOCK, (VARIANT == 2) ? 2 : DVO_REDUCE_WAVES_PE
             const int segn = seg + DVO_PX_PER_BLOCK;
             if (grp + 1 < g_hi && segn < count) {                         // (reads past `count` stay inside DVO_LIST_SLACK)
 #pragma unroll
-                for (int j = 0; j < DVO_PX_PER_THREAD; ++j) rn[j] = *reinterpret_cast<const uint2*>(list + segn + j * 64 + lane_);
+                for (int j = 0; j < DVO_PX_PER_THREAD; ++j) rn[j] = dvo_rec_load<DVO_NT_RECORDS(TAG)>(reinterpret_cast<const uint2*>(list + segn + j * 64 + lane_));
             }
         }
         // phase A for all pixels of the lane, then all tap loads back to back (memory-level parallelism: the
