@@ -398,7 +398,11 @@ __global__ __launch_bounds__(DVO_BLOCK) void k_ingest_level_fused(const DvoBatch
                     const int gy = (c[2][i] + 2 * c[2][i + 1] + c[2][i + 2]) - (c[0][i] + 2 * c[0][i + 1] + c[0][i + 2]);
                     out[i] = (uint32_t)c[1][i + 1] | (((uint32_t)gx & 0xfffu) << 8) | (((uint32_t)gy & 0xfffu) << 20);
                 }
-                *reinterpret_cast<uint4*>(packed + (size_t)y * g.pitch + x) = make_uint4(out[0], out[1], out[2], out[3]);
+                {   // non-temporal: the packed plane is next read by the reduction launches (it would only displace their data)
+                    uint32_t* pd = packed + (size_t)y * g.pitch + x;
+                    __builtin_nontemporal_store(out[0], pd); __builtin_nontemporal_store(out[1], pd + 1);
+                    __builtin_nontemporal_store(out[2], pd + 2); __builtin_nontemporal_store(out[3], pd + 3);
+                }
                 const uint32_t da = ds[tr * ING_DP + ING_PAD + 2 * cg], db = ds[tr * ING_DP + ING_PAD + 2 * cg + 1];
                 if (copy) {
                     *reinterpret_cast<uint32_t*>(dg + (size_t)y * w + x) = gs[tr * ING_GP + ING_PAD + cg];
@@ -557,7 +561,12 @@ __device__ __forceinline__ void list_seg_emit(const DvoBatchIngestParams& p, uin
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        for (int i = lane; i < cnt_h; i += 64) list[base + i] = st[i];
+        // non-temporal stores: the records are next read by the reduction launches, long after the caches have turned over
+        for (int i = lane; i < cnt_h; i += 64) {
+            const DvoPointRec r = st[i];
+            __builtin_nontemporal_store(((unsigned long long)r.pix << 32) | (unsigned long long)__float_as_uint(r.z),
+                                        reinterpret_cast<unsigned long long*>(list + base + i));
+        }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
