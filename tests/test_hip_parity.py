@@ -4,6 +4,8 @@ vectors of the reference run — on the same inputs.  Run on the GPU box with `p
 Tolerances (stated by BASELINE.json north_star): SE(3) increments within 1e-5 relative; everything that is
 integer / index work (pyramids, Sobel planes, validity masks, warped coordinates) is bit-exact.
 """
+import os
+
 import numpy as np
 import pytest
 import scipy.linalg
@@ -734,7 +736,7 @@ def test_degenerate_poses_give_empty_systems(hip):
     np.testing.assert_array_equal(res["T"][0], Tfar[:3])
 
 
-@pytest.mark.parametrize("seed", [0, 1, 2, 3, 4, 5])
+@pytest.mark.parametrize("seed", list(range(int(os.environ.get("DVO_FUZZ_SEEDS", "6")))))      # DVO_FUZZ_SEEDS=200 for a longer soak
 def test_fuzz_random_geometry_vs_oracle(seed):
     """Random image sizes (odd, not multiples of 4 or 64), intrinsics with and without skew, several depth scales, random
     depth-valid fractions (0.4 .. 1.0), random poses and weights: valid-point lists, validity and warped coordinates
@@ -753,7 +755,7 @@ def test_fuzz_random_geometry_vs_oracle(seed):
     g2 = np.clip(np.roll(tex, int(rng.integers(-2, 3)), axis=1) + rng.normal(0, 3, (h, w)), 0, 255).astype(np.uint8)
     depth = rng.integers(2000, 30000, size=(h, w)).astype(np.uint16)
     depth[rng.random((h, w)) < rng.uniform(0.0, 0.6)] = 0
-    depth_scale = [0.0002, 1.0 / 5000.0, 0.001, 1.0 / 3.0e4, float(rng.uniform(1e-4, 1e-3)), 1.0][seed]
+    depth_scale = [0.0002, 1.0 / 5000.0, 0.001, 1.0 / 3.0e4, float(rng.uniform(1e-4, 1e-3)), 1.0][seed % 6]
     skew = 0.0 if seed % 2 == 0 else float(rng.uniform(-3, 3))
     K = np.array([[rng.uniform(0.7, 1.4) * w, skew, w / 2 + rng.uniform(-5, 5)],
                   [0, rng.uniform(0.7, 1.4) * w, h / 2 + rng.uniform(-5, 5)], [0, 0, 1]], dtype=np.float32)
