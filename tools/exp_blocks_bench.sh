@@ -1,6 +1,6 @@
 #!/bin/bash
 # Workgroups per launch of the reduction (DVO_TARGET_BLOCKS / DVO_MAX_GROUPS), measured on the whole default job (4 streams).
-for cfg in "default default" "1024 24" "1024 32" "1024 48" "1280 64" "640 128" "2560 32" "default default"; do
+for cfg in "default default" "1024 20" "1024 38" "1024 75" "1024 150" "512 75"; do
   set -- $cfg
   if [ "$1" = default ]; then unset DVO_TARGET_BLOCKS DVO_MAX_GROUPS; else export DVO_TARGET_BLOCKS=$1 DVO_MAX_GROUPS=$2; fi
   python bench.py --steps 10 --warmup 2 --no-cpu-baseline 2>/dev/null | python -c "
