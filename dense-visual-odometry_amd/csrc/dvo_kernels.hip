@@ -13,6 +13,13 @@
 //   k_sum_partials     K4  deterministic fixed-order sum of the per-workgroup partials
 //   k_dense<...>       K5  dense r / J / valid / uv writer (return contract of compute_residuals_and_jacobian)
 //   k_init_state, k_level_begin, k_solve, k_finish   device-side Gauss-Newton control (base_robust_dvo.py:152-232)
+//   k_gn_small<...>        every iteration of the coarse levels of one pair in one persistent workgroup (reduction + control)
+//   k_ingest_level_fused<TW>  one pass per level: planes, Sobel + pack, next level's median pyramid, valid-pixel counts
+//   k_list_scan, k_list_build  valid-point lists (records {z, x | y | I} of the pixels with depth != 0, raster order)
+//   k_batch_bgr_ingest     batched colour conversion + depth clamp in front of the level-0 pass
+//
+// Template parameter VARIANT: 0 = V1 (reference CPU default), 1 = V2 (approximate_image2_gradient), 2 = V3 (numba.cuda kernel
+// semantics), 3 = GN (build-defined: V1 with the gradient normalised and J_w at the warped point).
 //
 // References are relative to /root/reference/src/dense_visual_odometry/.
 #include "dvo_internal.h"
