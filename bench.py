@@ -199,6 +199,7 @@ def main():
     import torch.distributed as dist
 
     rank, local_rank, world = launch.rank_env()
+    launch.mark_rank("started")
     try:
         launch.check_world(args.gpus)
     except launch.LaunchError as e:
@@ -235,7 +236,7 @@ def main():
                          reference_variant={"v3": "cuda", "gn": "gn"}.get(args.variant, "cpu"),
                          level_iterations=([int(v) for v in args.level_iterations.split(",")] if args.level_iterations else None))
     if use_dist:
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank), timeout=launch.pg_timeout())
         world = dist.get_world_size()                      # the ranks that actually joined
         if world != args.gpus:
             raise SystemExit("bench.py: %d ranks joined the process group, --gpus %d" % (world, args.gpus))
@@ -373,6 +374,7 @@ def main():
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
+    launch.mark_rank("done")
 
 
 if __name__ == "__main__":

@@ -89,6 +89,9 @@ struct dvo_ctx {
     double* d_scale1 = nullptr;          // Student-t device solve: per-workgroup sums of the two scale passes
     double* d_scale2 = nullptr;
     float* d_rcache = nullptr;           // Student-t device solve: residuals kept between the scale passes [max_pairs][max_w*max_h]
+    uint32_t* d_exp_gradh = nullptr;     // DVO_EXP_TAPS side planes [n_slots][exp_plane_texels]: {f16 gx, f16 gy} / intensity
+    uint8_t* d_exp_ipl = nullptr;
+    size_t exp_plane_texels = 0;
     float* d_dense = nullptr;            // dense writer outputs: r[npix] J[6 npix] uv[2 npix] + valid
     double* d_trace = nullptr;
     int trace_cap = 0;
@@ -132,6 +135,8 @@ struct dvo_ctx {
         int small_max_pix = 19200;      // DVO_SMALL_MAX_PIX: levels with at most this many pixels run in the persistent per-pair
                                         // kernel k_gn_small (0: every level takes the per-iteration launches)
         int small_threads = 0;          // DVO_SMALL_THREADS: workgroup size of k_gn_small (0: chosen from the batch size)
+        int exp_taps = 0;               // DVO_EXP_TAPS=1..4: dvo_normal_equations (V1, unweighted) runs an experimental tap
+                                        // formulation of the reduction (dvo_exp_taps.inc; tools/exp_taps.py); never the solve path
     } knobs;
     char err[512] = "";
 };
@@ -274,7 +279,8 @@ void drain_profile(dvo_ctx* ctx)
 }
 
 // one launch of the reduction kernel, optionally bracketed by events
-hipError_t launch_reduce_profiled(dvo_ctx* ctx, const DvoReduceParams& p, int level, int variant, int weight_mode, int scale_pass)
+hipError_t launch_reduce_profiled(dvo_ctx* ctx, const DvoReduceParams& p, int level, int variant, int weight_mode, int scale_pass,
+                                  int exp_mode = 0)
 {
     hipEvent_t a = nullptr, b = nullptr;
     if (ctx->profiling) {
@@ -283,7 +289,8 @@ hipError_t launch_reduce_profiled(dvo_ctx* ctx, const DvoReduceParams& p, int le
         b = pool_event(ctx);
         if (a && b) (void)hipEventRecord(a, ctx->stream);
     }
-    hipError_t e = dvo_launch_reduce(p, variant, weight_mode, scale_pass, ctx->stream);
+    hipError_t e = exp_mode ? dvo_launch_reduce_exp(p, exp_mode, ctx->d_exp_gradh, ctx->d_exp_ipl, ctx->exp_plane_texels, ctx->stream)
+                            : dvo_launch_reduce(p, variant, weight_mode, scale_pass, ctx->stream);
     if (ctx->profiling && a && b) {
         (void)hipEventRecord(b, ctx->stream);
         ctx->pending.push_back({a, b, level});
@@ -487,6 +494,8 @@ int dvo_create(int device, int max_w, int max_h, int max_levels, int n_slots, in
         ctx->knobs.st_solve_phases = getenv("DVO_ST_SOLVE_PHASES") != nullptr;
         ctx->knobs.no_rcache = getenv("DVO_NO_RCACHE") != nullptr;
         ctx->knobs.ingest_unfused = getenv("DVO_INGEST_UNFUSED") != nullptr;
+        e = getenv("DVO_EXP_TAPS");
+        if (e) ctx->knobs.exp_taps = atoi(e);
         e = getenv("DVO_SMALL_MAX_PIX");
         if (e) ctx->knobs.small_max_pix = atoi(e);
         e = getenv("DVO_SMALL_THREADS");
@@ -516,7 +525,8 @@ void dvo_destroy(dvo_ctx* ctx)
     if (ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);
     void* dev[] = {ctx->d_slots, ctx->d_prev, ctx->d_cur, ctx->d_T, ctx->d_Tinit, ctx->d_wparam, ctx->d_active, ctx->d_partials,
                    ctx->d_out, ctx->d_state, ctx->d_xi, ctx->d_iters, ctx->d_err, ctx->d_stage_img, ctx->d_dense, ctx->d_trace, ctx->d_frame_slots, ctx->d_prior, ctx->d_batch_stage,
-                   ctx->d_list_count, ctx->d_seg_counts, ctx->d_rcache, ctx->d_scale1, ctx->d_scale2, ctx->d_irls_done};
+                   ctx->d_list_count, ctx->d_seg_counts, ctx->d_rcache, ctx->d_scale1, ctx->d_scale2, ctx->d_irls_done,
+                   ctx->d_exp_gradh, ctx->d_exp_ipl};
     for (void* p : dev) if (p) (void)hipFree(p);
     void* host[] = {ctx->hs.prev, ctx->hs.cur, ctx->hs.T, ctx->hs.wparam, ctx->hs.out, ctx->hs.xi, ctx->hs.iters, ctx->hs.err, ctx->h_frame_slots, ctx->h_prior};
     for (void* p : host) if (p) (void)hipHostFree(p);
@@ -956,7 +966,21 @@ int dvo_normal_equations(dvo_ctx* ctx, int level, int n_pairs, const int* prev_s
     DvoReduceParams p;
     rc = fill_reduce_params(ctx, level, n_pairs, w, h, &p);
     if (rc) return rc;
-    HIP_TRY(ctx, launch_reduce_profiled(ctx, p, level, variant, weight_mode, 0));
+    int exp_mode = 0;
+    if (ctx->knobs.exp_taps && variant == DVO_VARIANT_V1 && weight_mode == 0 && p.cam.skew0) {
+        // experimental tap formulations: side planes of the current frames, rebuilt on every call (test hook, not timed)
+        exp_mode = ctx->knobs.exp_taps;
+        if (!ctx->d_exp_gradh) {
+            DvoLevelGeom g0[DVO_MAX_LEVELS];
+            level_geometry(ctx->max_w, ctx->max_h, 1, g0, nullptr);
+            ctx->exp_plane_texels = align_up((size_t)(g0[0].h + 1) * g0[0].pitch + 64, 64);
+            HIP_TRY(ctx, hipMalloc(&ctx->d_exp_gradh, (size_t)ctx->n_slots * ctx->exp_plane_texels * 4 + 8192));
+            HIP_TRY(ctx, hipMalloc(&ctx->d_exp_ipl, (size_t)ctx->n_slots * ctx->exp_plane_texels + 8192));
+        }
+        HIP_TRY(ctx, dvo_launch_exp_convert(ctx->d_slots, ctx->slot_stride, p.g, ctx->d_cur, n_pairs, ctx->d_exp_gradh, ctx->d_exp_ipl,
+                                            ctx->exp_plane_texels, ctx->stream));
+    }
+    HIP_TRY(ctx, launch_reduce_profiled(ctx, p, level, variant, weight_mode, 0, exp_mode));
     HIP_TRY(ctx, dvo_launch_sum_partials(ctx->d_partials, p.blocks_per_pair, n_pairs, ctx->d_out, ctx->stream));
     HIP_TRY(ctx, hipMemcpyAsync(ctx->hs.out, ctx->d_out, (size_t)n_pairs * DVO_STRIDE * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));

@@ -188,3 +188,8 @@ hipError_t dvo_launch_gn_small(const DvoSmallParams& p, int variant, int threads
 hipError_t dvo_launch_debug_divide(const float* a, const float* b, float* out, float* ref, int n, hipStream_t s);
 hipError_t dvo_launch_finish(const DvoPairState* st, int n_pairs, double* xi_out, int* iters_out, double* err_out,
                              hipStream_t s);
+// experimental tap formulations of the level-0 reduction (dvo_exp_taps.inc; DVO_EXP_TAPS knob, tools/exp_taps.py)
+hipError_t dvo_launch_exp_convert(const uint8_t* slots, size_t slot_stride, const DvoLevelGeom& g, const int* slot_ids, int n_slots,
+                                  uint32_t* gradh, uint8_t* ipl, size_t plane_texels, hipStream_t s);
+hipError_t dvo_launch_reduce_exp(const DvoReduceParams& p, int mode, const uint32_t* gradh, const uint8_t* ipl, size_t plane_texels,
+                                 hipStream_t s);

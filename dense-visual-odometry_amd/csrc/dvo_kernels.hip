@@ -742,13 +742,22 @@ __device__ __forceinline__ void unpack_tap(uint32_t p, float& I, float& gx, floa
     gy = (float)(((int32_t)p) >> 20);
 }
 
+// a / b, correctly rounded, from the refined reciprocal rb = v_rcp_f32(b) + one Newton step: one residual correction of the
+// product (Markstein's sequence).  tools/ubench/quotient3.hip compared it on the device with the IEEE division over 3.4e10
+// operand pairs in and far beyond the projection's ranges and over EVERY float32 mantissa of b (incl. the all-ones patterns the
+// theorem excepts) x 192 numerators: no mismatch (profiles/r03_experiments.txt); the GPU suite repeats a 50 M-pair check
+// (test_projection_division_is_bit_identical_to_ieee).  DVO_DIV_TWO_STEPS restores the two-correction form of rounds 1-2.
 __device__ __forceinline__ float dvo_div_with_rcp(float a, float b, float rb)
 {
     const float q0 = a * rb;
     const float e0 = fmaf(-b, q0, a);
     const float q1 = fmaf(e0, rb, q0);
+#ifdef DVO_DIV_TWO_STEPS
     const float e1 = fmaf(-b, q1, a);
     return fmaf(e1, rb, q1);
+#else
+    return q1;
+#endif
 }
 
 // SKEW = false: the camera matrix has no skew term (K[0][1] == 0), so the zero products of the reference's matrix
@@ -771,12 +780,12 @@ __device__ __forceinline__ void dvo_geo(const DvoLevelGeom& g, const DvoLevelCam
     const float zp = ((T[8] * x + T[9] * y) + T[10] * z) + T[11];
     const float un = SKEW ? (((cam.fx * xp) + (cam.s * yp)) + (cam.cx * zp)) : ((cam.fx * xp) + (cam.cx * zp));
     const float vn = (cam.fy * yp) + (cam.cy * zp);
-    // Correctly rounded quotients.  This is exactly the arithmetic core of the compiler's IEEE float32 division
-    // (v_rcp_f32, two Newton steps on the reciprocal/quotient, final fma) without the v_div_scale / v_div_fixup
-    // wrappers, which only rescale when the quotient or an intermediate leaves the normal range (|a/b| beyond
-    // 2^+-96, denormals) and patch up inf / NaN / 0: for pixel coordinates (|a/b| < 1e5, |b| ~ 1) they are
-    // identities, and 1/zp is shared by both quotients.  A non-finite or zero zp gives NaN here instead of +-inf:
-    // invalid either way.  Checked bit for bit against `/` in tests (dvo_debug_divide).
+    // Correctly rounded quotients: v_rcp_f32 refined by one Newton step (shared by both quotients), then per quotient the
+    // product and one residual correction (dvo_div_with_rcp) -- the arithmetic core of an IEEE float32 division without the
+    // v_div_scale / v_div_fixup wrappers, which only rescale when the quotient or an intermediate leaves the normal range
+    // (|a/b| beyond 2^+-96, denormals) and patch up inf / NaN / 0: for pixel coordinates (|a/b| < 1e5, |b| ~ 1) they are
+    // identities.  A non-finite or zero zp gives NaN here instead of +-inf: invalid either way.  Checked bit for bit
+    // against `/` in tests (dvo_debug_divide) and by tools/ubench/quotient3.hip.
     const float rz0 = __builtin_amdgcn_rcpf(zp);
     const float rz = fmaf(fmaf(-zp, rz0, 1.0f), rz0, rz0);
     const float uw = dvo_div_with_rcp(un, zp, rz);
@@ -856,29 +865,30 @@ __device__ __forceinline__ void dvo_geo_v3(const DvoLevelGeom& g, const DvoLevel
 // 2 (V3): Jacobian row already finished by dvo_geo_v3, only the residual is computed here;
 // 3 (GN, build-defined): V1's sampling with the Sobel response normalised (1/8: a unit derivative) and J_w at the warped
 // point (dvo_geo<.., true>), i.e. the true Gauss-Newton row of the forward-compositional photometric error.
+// The taps as float32 values, in the order (y0,x0) (y0,x1) (y1,x0) (y1,x1); own = gradient of I1 at the pixel (V2).
+struct PixelTapsF {
+    float I[4], gx[4], gy[4];
+    float own_gx, own_gy;
+};
+
 template <int VARIANT, bool NEED_J>
-__device__ __forceinline__ void dvo_finish(const DvoLevelCam& cam, const PixelGeo& q, const PixelTaps& t,
-                                           unsigned i1, PixelOut& o)
+__device__ __forceinline__ void dvo_finish_f(const DvoLevelCam& cam, const PixelGeo& q, const PixelTapsF& t,
+                                             unsigned i1, PixelOut& o)
 {
     // --- bilinear weights (cpu_robust...:202-254) ------------------------------------------------------
     const float ax = q.ax, ay = q.ay;                      // uw - floor(uw), vw - floor(vw): exact
     const float bx = 1.0f - ax, by = 1.0f - ay;            // == (x0+1) - x up to one rounding when x < 1
     const float w00 = bx * by, w01 = bx * ay, w10 = ax * by, w11 = ax * ay;
-    float I00, I10, I01, I11, gx00, gx10, gx01, gx11, gy00, gy10, gy01, gy11;
-    unpack_tap(t.t0.a, I00, gx00, gy00);
-    unpack_tap(t.t0.b, I10, gx10, gy10);
-    unpack_tap(t.t1.a, I01, gx01, gy01);
-    unpack_tap(t.t1.b, I11, gx11, gy11);
-    const float i2 = fmaf(w11, I11, fmaf(w10, I10, fmaf(w01, I01, w00 * I00)));
+    const float i2 = fmaf(w11, t.I[3], fmaf(w10, t.I[1], fmaf(w01, t.I[2], w00 * t.I[0])));
     o.r = i2 - (float)i1;                                                       // :191-194
     if (!NEED_J || VARIANT == 2) return;        // V3: the Jacobian row was finished in phase A (dvo_geo_v3)
     float gxw, gyw;
     if (VARIANT == 0 || VARIANT == 3) {
-        gxw = fmaf(w11, gx11, fmaf(w10, gx10, fmaf(w01, gx01, w00 * gx00)));    // :123-128
-        gyw = fmaf(w11, gy11, fmaf(w10, gy10, fmaf(w01, gy01, w00 * gy00)));
+        gxw = fmaf(w11, t.gx[3], fmaf(w10, t.gx[1], fmaf(w01, t.gx[2], w00 * t.gx[0])));    // :123-128
+        gyw = fmaf(w11, t.gy[3], fmaf(w10, t.gy[1], fmaf(w01, t.gy[2], w00 * t.gy[0])));
     } else {
-        float Ip;
-        unpack_tap(t.own, Ip, gxw, gyw);                                        // :69-75 (Sobel of I1 at the pixel)
+        gxw = t.own_gx;                                                         // :69-75 (Sobel of I1 at the pixel)
+        gyw = t.own_gy;
     }
     // --- J_w at the UN-warped point (utils/jacobian.py:39-42, quirk Q2) ------------------------------
     // x/z and y/z are the normalised coordinates the point was built from (x = xn * z), and 1/z is v_rcp_f32 (1 ulp):
@@ -896,6 +906,20 @@ __device__ __forceinline__ void dvo_finish(const DvoLevelCam& cam, const PixelGe
     o.J[3] = -fmaf(b, m, qq);
     o.J[4] = fmaf(a, m, p);
     o.J[5] = fmaf(qq, a, -(p * b));
+}
+
+template <int VARIANT, bool NEED_J>
+__device__ __forceinline__ void dvo_finish(const DvoLevelCam& cam, const PixelGeo& q, const PixelTaps& t,
+                                           unsigned i1, PixelOut& o)
+{
+    PixelTapsF f;
+    unpack_tap(t.t0.a, f.I[0], f.gx[0], f.gy[0]);
+    unpack_tap(t.t0.b, f.I[1], f.gx[1], f.gy[1]);
+    unpack_tap(t.t1.a, f.I[2], f.gx[2], f.gy[2]);
+    unpack_tap(t.t1.b, f.I[3], f.gx[3], f.gy[3]);
+    f.own_gx = f.own_gy = 0.0f;
+    if (NEED_J && VARIANT == 1) { float Ip; unpack_tap(t.own, Ip, f.own_gx, f.own_gy); }
+    dvo_finish_f<VARIANT, NEED_J>(cam, q, f, i1, o);
 }
 
 // Test hook: out[i] = the kernels' quotient a[i]/b[i]; ref[i] = the compiler's IEEE division.
@@ -933,11 +957,12 @@ __device__ __forceinline__ double wave_sum(double v)
 // DVO_CLOCK_PROBE (diagnostic build, tools/clock_probe.py; never in the product library): the two reserved slots of the
 // record carry, summed over the workgroups of a pair, the shader-clock ticks (s_memtime) and the constant 100 MHz ticks
 // (s_memrealtime) each workgroup's first wave spent in the kernel body: their ratio is the clock the chip really holds.
-__device__ __forceinline__ void block_reduce_terms(const float* acc, double* out, unsigned long long t0 = 0, unsigned long long r0 = 0)
+#define DVO_REDUCE_TBUF_FLOATS (15 * 8 * 33)             // LDS floats block_reduce_terms_buf needs (15.5 KB)
+__device__ __forceinline__ void block_reduce_terms_buf(const float* acc, double* out, float* tbuf /* LDS [DVO_REDUCE_TBUF_FLOATS] */,
+                                                       unsigned long long t0 = 0, unsigned long long r0 = 0)
 {
     constexpr int ROW = 8 * 33;                          // 8 segments of 32 values + 1 pad each
     constexpr int HALF = 15;
-    __shared__ float tbuf[HALF * ROW];
     const int t = threadIdx.x;
     const int wpos = (t >> 5) * 33 + (t & 31);
     const int term = t >> 3, segi = t & 7;
@@ -964,6 +989,12 @@ __device__ __forceinline__ void block_reduce_terms(const float* acc, double* out
 #else
     if (t >= 30 && t < DVO_STRIDE) out[t] = 0.0;
 #endif
+}
+
+__device__ __forceinline__ void block_reduce_terms(const float* acc, double* out, unsigned long long t0 = 0, unsigned long long r0 = 0)
+{
+    __shared__ float tbuf[DVO_REDUCE_TBUF_FLOATS];
+    block_reduce_terms_buf(acc, out, tbuf, t0, r0);
 }
 
 #ifndef DVO_REDUCE_WAVES_PER_SIMD
@@ -2140,3 +2171,5 @@ hipError_t dvo_launch_finish(const DvoPairState* st, int n_pairs, double* xi_out
     hipLaunchKernelGGL(k_finish, dim3((n_pairs + 63) / 64), dim3(64), 0, s, st, n_pairs, xi_out, iters_out, err_out);
     return hipGetLastError();
 }
+
+#include "dvo_exp_taps.inc"

@@ -107,7 +107,7 @@ def load_library() -> C.CDLL:
             "`make -C dense-visual-odometry_amd/csrc`; this package has no CPU fallback".format(_LIB_PATH))
     # One HIP runtime per process: PyTorch-ROCm ships its own libamdhip64 and loads it by path, so when libdvo_hip.so (linked
     # against the system ROCm) comes first the process ends up with two runtimes and torch.cuda then reports "No HIP GPUs are
-    # available" (measured, tools/order_test.py).  With torch imported first the loader resolves this library's libamdhip64
+    # available" (measured, tools/hip_load_order.py).  With torch imported first the loader resolves this library's libamdhip64
     # dependency to the copy already in the process.  Hosts without PyTorch (plain C, or Python without torch) are unaffected.
     try:
         import torch  # noqa: F401

@@ -57,30 +57,103 @@ def check_world(requested_gpus: int, env=None) -> int:
     return world
 
 
+DEFAULT_TIMEOUT_S = 1800.0        # a rank stuck in rendezvous / RCCL init must not hang the command until the caller's own limit
+
+
+def default_timeout() -> float:
+    """Seconds after which `launch_ranks` gives up (DVO_LAUNCH_TIMEOUT overrides; <= 0 means no limit)."""
+    try:
+        return float(os.environ.get("DVO_LAUNCH_TIMEOUT", DEFAULT_TIMEOUT_S))
+    except ValueError:
+        return DEFAULT_TIMEOUT_S
+
+
+def mark_rank(state: str, env=None) -> None:
+    """Inside a rank: leave a `rank<k>.<state>` marker ("started", "done") in the launcher's status directory, so that a
+    launcher that times out can name the ranks that never started or never finished.  No-op without a launcher."""
+    env = os.environ if env is None else env
+    d = env.get("DVO_LAUNCH_STATUS_DIR")
+    if not d:
+        return
+    try:
+        with open(os.path.join(d, "rank{}.{}".format(env.get("RANK", "0"), state)), "w") as f:
+            f.write(str(os.getpid()))
+    except OSError:
+        pass
+
+
+def _unfinished(status_dir: str, n_ranks: int) -> str:
+    names = set(os.listdir(status_dir)) if os.path.isdir(status_dir) else set()
+    never = [k for k in range(n_ranks) if "rank{}.started".format(k) not in names]
+    stuck = [k for k in range(n_ranks) if "rank{}.started".format(k) in names and "rank{}.done".format(k) not in names]
+    return "ranks that never reported in: {}; ranks that started but did not finish: {}".format(never or "none", stuck or "none")
+
+
+def _kill_group(proc: subprocess.Popen, grace: float = 5.0) -> None:
+    """SIGTERM, then SIGKILL, to the whole process group of the launcher child (torch.distributed.run AND its ranks: killing
+    only the parent would orphan the ranks with the GPUs still held)."""
+    import signal
+    for sig, wait in ((signal.SIGTERM, grace), (signal.SIGKILL, 10.0)):
+        try:
+            os.killpg(proc.pid, sig)
+        except (ProcessLookupError, PermissionError):
+            pass
+        try:
+            proc.wait(timeout=wait)
+        except subprocess.TimeoutExpired:
+            continue
+        # the group leader is gone; make sure no rank of the group outlives it
+        try:
+            os.killpg(proc.pid, signal.SIGKILL)
+        except (ProcessLookupError, PermissionError):
+            pass
+        return
+
+
 def launch_ranks(n_ranks: int, script: str, argv: Sequence[str], need_devices: bool = True,
                  extra_env: Optional[dict] = None, timeout: Optional[float] = None) -> int:
     """Runs `script argv...` as n_ranks processes (one per GPU) under torch.distributed.run and returns the exit code.
     The children's stdout / stderr are inherited, so rank 0's JSON line is this process's output too.
-    need_devices: fail (LaunchError) when fewer than n_ranks HIP devices are visible instead of degrading."""
+    need_devices: fail (LaunchError) when fewer than n_ranks HIP devices are visible instead of degrading.
+    timeout: seconds (default `default_timeout()`, 30 min; <= 0: none).  On expiry the whole process group of the launcher is
+    terminated (no rank survives) and LaunchError names the ranks that did not report in / did not finish."""
     if n_ranks < 1:
         raise LaunchError("n_ranks must be >= 1")
     if need_devices:
         have = visible_devices()
         if have < n_ranks:
             raise LaunchError("{} GPUs requested but only {} HIP device(s) visible".format(n_ranks, have))
+    if timeout is None:
+        timeout = default_timeout()
+    if timeout is not None and timeout <= 0:
+        timeout = None
+    import tempfile
     env = dict(os.environ)
-    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "GROUP_RANK", "ROLE_RANK"):
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "GROUP_RANK", "ROLE_RANK", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC only on this pool (RCCL across processes)
     env.setdefault("OMP_NUM_THREADS", "1")
     if extra_env:
         env.update(extra_env)
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n_ranks),
-           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), script] + list(argv)
-    proc = subprocess.Popen(cmd, env=env)
-    try:
-        return proc.wait(timeout=timeout)
-    except subprocess.TimeoutExpired:
-        proc.kill()
-        proc.wait()
-        raise LaunchError("ranks did not finish within {} s".format(timeout))
+    with tempfile.TemporaryDirectory(prefix="dvo_launch_") as status_dir:
+        env["DVO_LAUNCH_STATUS_DIR"] = status_dir
+        # --standalone: the rendezvous store picks its own port on 127.0.0.1 (no free-port probe that another process could win)
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--standalone", "--local-addr", "127.0.0.1", "--nnodes=1",
+               "--nproc-per-node", str(n_ranks), script] + list(argv)
+        proc = subprocess.Popen(cmd, env=env, start_new_session=True)      # own process group: see _kill_group
+        try:
+            return proc.wait(timeout=timeout)
+        except subprocess.TimeoutExpired:
+            why = _unfinished(status_dir, n_ranks)
+            _kill_group(proc)
+            raise LaunchError("{} rank(s) did not finish within {:.0f} s and were terminated ({})".format(n_ranks, timeout, why))
+        except BaseException:
+            _kill_group(proc)
+            raise
+
+
+def pg_timeout():
+    """timedelta for torch.distributed.init_process_group: a rank that cannot reach its peers fails with a message instead of
+    waiting for the default 10-30 minutes."""
+    import datetime
+    return datetime.timedelta(seconds=float(os.environ.get("DVO_PG_TIMEOUT", "300")))

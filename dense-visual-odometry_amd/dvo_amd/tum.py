@@ -101,17 +101,22 @@ def load_tum_sequence(root: Path, size: Optional[int] = None) -> TumSequence:
     return TumSequence(root, stamps, rgb_paths, depth_paths, gt_T, gt_t)
 
 
-def read_frame(rgb_path: str, depth_path: str) -> Tuple[np.ndarray, np.ndarray]:
-    """-> (BGR u8 HxWx3, depth u16 HxW), the array layout cv2.imread gives the reference."""
+def read_frame(rgb_path: str, depth_path: str, channel_order: str = "bgr") -> Tuple[np.ndarray, np.ndarray]:
+    """-> (colour u8 HxWx3, depth u16 HxW).  channel_order "bgr" (default): the array layout cv2.imread gives, which is what
+    the BGR2GRAY ingest expects.  "rgb": what the reference's CLI really hands to step() — its loader converts the image to RGB
+    (src/test_dvo.py:183) and step() then applies BGR2GRAY to it (core/base_dense_visual_odometry.py:58), i.e. red and blue
+    weights swapped; only for like-for-like comparisons with runs of that CLI (tools/run_sequence.py --reference-cli-compat)."""
+    if channel_order not in ("bgr", "rgb"):
+        raise ValueError("channel_order must be 'bgr' or 'rgb'")
     from PIL import Image
     rgb = np.array(Image.open(rgb_path).convert("RGB"))
     depth = np.array(Image.open(depth_path)).astype(np.uint16)
-    return np.ascontiguousarray(rgb[..., ::-1]), depth
+    return (np.ascontiguousarray(rgb) if channel_order == "rgb" else np.ascontiguousarray(rgb[..., ::-1])), depth
 
 
-def iter_frames(seq: TumSequence) -> Iterator[Tuple[np.ndarray, np.ndarray]]:
+def iter_frames(seq: TumSequence, channel_order: str = "bgr") -> Iterator[Tuple[np.ndarray, np.ndarray]]:
     for rp, dp in zip(seq.rgb_paths, seq.depth_paths):
-        yield read_frame(rp, dp)
+        yield read_frame(rp, dp, channel_order)
 
 
 def write_tum_trajectory(path: Path, timestamps, T_wc) -> None:

@@ -35,7 +35,7 @@ meta.json): compute_jacobian_of_warp_function (utils/jacobian.py:7-44), _fill_ja
 vectorised form accumulates in float64 as numba's type inference does, the interpreted loop
 accumulates in float32).
 
-Outputs (tests/golden/): frames.npz (inputs), pairs_l4.npz, single_l1.npz, weighted_l4.npz,
+Outputs (tests/golden/): frames.npz (inputs), cli_compat.npz, pairs_l4.npz, single_l1.npz, weighted_l4.npz,
 approx_l4.npz, sigma_l4.npz, dense_rj.npz, tiny10.npz, sequence.npz, lie.npz, bilinear_ref.npz, meta.json.
 """
 import json
@@ -323,10 +323,36 @@ def sigma_case(cam, frames, sigma=1e-13, n_frames=4):
     print("S sigma=%g: iterations per pair %s, xi=%s" % (sigma, np.bincount(out["pair"]).tolist(), out["final_xi"]), flush=True)
 
 
+def cli_compat_case(cam, data_dir, gt):
+    """The data flow of the reference's CLI on colour input (src/test_dvo.py:183 + core/base_dense_visual_odometry.py:58): the
+    loader converts what imread returns to RGB and step() then applies BGR2GRAY to it, i.e. the red and blue weights are
+    swapped.  Fixture frames 1, 2 through exactly those calls and the reference's step() (4 levels x 10 iterations):
+    the gray planes the solver really sees and the transform it estimates -> cli_compat.npz."""
+    rgb, depth = [], []
+    for i in (1, 2):
+        rgb.append(cv2.cvtColor(cv2.imread(str(data_dir / gt[str(i)]["rgb"]), cv2.IMREAD_ANYCOLOR), cv2.COLOR_BGR2RGB))     # test_dvo.py:183
+        depth.append(cv2.imread(str(data_dir / gt[str(i)]["depth"]), cv2.IMREAD_UNCHANGED))                                  # :184
+    dvo = get_dvo("robust-dvo", cam, Se3.identity(), levels=4, max_iterations=10)
+    dvo.step(color_image=rgb[0], depth_image=depth[0].copy())
+    tf = dvo.step(color_image=rgb[1], depth_image=depth[1].copy())
+    a = se3_to_arrays(tf)
+    np.savez_compressed(OUT / "cli_compat.npz", rgb_1=rgb[0], rgb_2=rgb[1], depth_1=depth[0], depth_2=depth[1],
+                        gray_cli_1=cv2.cvtColor(rgb[0], cv2.COLOR_BGR2GRAY), gray_cli_2=cv2.cvtColor(rgb[1], cv2.COLOR_BGR2GRAY),
+                        tf_T=a["T"], tf_xi=a["xi"])
+    print("C cli-compat pair (1,2): xi=%s" % a["xi"], flush=True)
+
+
 def main():
     t_start = time.time()
     OUT.mkdir(parents=True, exist_ok=True)
     install_patches()
+    if "--only-cli-compat" in sys.argv:
+        install_fast_loops()
+        data_dir = REF / "tests" / "test_data"
+        with (data_dir / "ground_truth.json").open() as fp:
+            gt = json.load(fp)
+        cli_compat_case(RGBDCameraModel.load_from_yaml(data_dir / "camera_intrinsics.yaml"), data_dir, gt)
+        return
     if "--only-sigma" in sys.argv:
         install_fast_loops()
         f = np.load(OUT / "frames.npz")
@@ -495,6 +521,7 @@ def main():
     np.savez_compressed(OUT / "lie.npz", **{k: np.stack(v) if isinstance(v, list) else v for k, v in lie.items()})
 
     sigma_case(cam, frames)
+    cli_compat_case(cam, data_dir, gt)
 
     meta["elapsed_s"] = time.time() - t_start
     with (OUT / "meta.json").open("w") as fp:

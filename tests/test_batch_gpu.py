@@ -414,6 +414,34 @@ def test_run_sequence_fixture_end_to_end(tmp_path, golden_dir, colour):
     assert len(stamps) == 10
 
 
+def test_run_sequence_reference_cli_compat(tmp_path, golden_dir):
+    """--reference-cli-compat: the colour fixture frames reach the BGR2GRAY ingest in RGB order, as in the reference's CLI
+    (src/test_dvo.py:183 + core/base_dense_visual_odometry.py:58).  The gray plane the device builds is bit-identical to the one
+    the reference run saw, and the estimated transform equals that run's (cli_compat.npz, oracle/refrun/make_golden.py)."""
+    import json
+    import subprocess
+    import sys
+    from pathlib import Path
+    import dvo_amd
+    c = np.load(golden_dir / "cli_compat.npz")
+    f = np.load(golden_dir / "frames.npz")
+    with dvo_amd.HipContext(max_w=640, max_h=480, max_levels=1, n_slots=2, max_pairs=1) as ctx:
+        ctx.set_camera(500, 500, 320, 240, 0, float(f["depth_scale"]))
+        ctx.upload_frame_bgr(0, c["rgb_1"], c["depth_1"].copy(), 1, 5.0)
+        assert np.array_equal(ctx.download_level(0, 0, want=("gray",))["gray"], c["gray_cli_1"])
+    root = Path(__file__).resolve().parents[1]
+    cmd = [sys.executable, str(root / "tools" / "run_sequence.py"), "--fixture", "--reference-cli-compat", "--out", str(tmp_path), "--window", "4"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=str(root))
+    assert out.returncode == 0, out.stderr[-3000:]
+    line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["frames"] == 2 and line["reference_cli_compat"] is True and line["input"].startswith("rgb fed as bgr")
+    rep = json.loads((tmp_path / "report.json").read_text())
+    np.testing.assert_allclose(np.array(rep["estimated_transforms"])[1], c["tf_xi"].reshape(6), atol=3e-6)
+    # the default (true BGR order) run of the same two frames gives a measurably different transform
+    g = np.load(golden_dir / "pairs_l4.npz")
+    assert np.max(np.abs(c["tf_xi"].reshape(6) - g["final_xi"][0].reshape(6))) > 1e-6
+
+
 def test_variant_gn_batched_with_weights_vs_oracle(vga_stream):
     """The build's true Gauss-Newton mode through the batched device solve, unweighted and with the three weightings, against the
     oracle's loop of the same definition (parity unpinned: no reference counterpart), 3 levels x 3 iterations."""

@@ -67,6 +67,54 @@ def test_rank_failure_is_the_launchers_exit_code(tmp_path):
     assert out.returncode == 1
 
 
+def test_timeout_terminates_every_rank_and_names_the_stuck_ones(tmp_path):
+    """A rank that hangs (stuck rendezvous / RCCL init on hardware) must not hang the command: launch_ranks gives up after its
+    timeout, raises LaunchError naming the ranks that did not finish, and leaves no process of the group behind."""
+    pidfile = tmp_path / "pids.txt"
+    stub = tmp_path / "sleepy_worker.py"
+    stub.write_text(
+        "import os, sys, time\n"
+        "sys.path.insert(0, os.environ['DVO_PKG_DIR'])\n"
+        "from dvo_amd import launch\n"
+        "open(%r, 'a').write('%%d\\n' %% os.getpid())\n"
+        "if os.environ['RANK'] == '0':\n"
+        "    launch.mark_rank('started'); launch.mark_rank('done'); sys.exit(0)\n"
+        "launch.mark_rank('started')\n"
+        "time.sleep(600)\n" % str(pidfile))
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "from dvo_amd import launch\n"
+            "try:\n"
+            "    launch.launch_ranks(2, %r, [], need_devices=False, timeout=25)\n"
+            "except launch.LaunchError as e:\n"
+            "    print('LAUNCH_ERROR', e); sys.exit(7)\n"
+            "sys.exit(0)\n" % (str(PKG), str(stub)))
+    out = _run_driver(code, timeout=120)
+    assert out.returncode == 7, out.stdout[-2000:] + out.stderr[-2000:]
+    assert "LAUNCH_ERROR" in out.stdout and "did not finish: [1]" in out.stdout, out.stdout
+    import time
+    time.sleep(1.0)
+    pids = [int(x) for x in pidfile.read_text().split()]
+    assert len(pids) == 2
+    for pid in pids:                                    # no rank survives the launcher
+        alive = True
+        try:
+            os.kill(pid, 0)
+            # a zombie of an already-reaped parent may linger for a moment; check its state
+            state = Path("/proc/%d/status" % pid).read_text().split("State:")[1].split()[0]
+            alive = state not in ("Z", "X")
+        except (ProcessLookupError, FileNotFoundError):
+            alive = False
+        assert not alive, "rank process %d survived the timeout" % pid
+
+
+def test_default_timeout_is_finite(monkeypatch):
+    monkeypatch.delenv("DVO_LAUNCH_TIMEOUT", raising=False)
+    assert 0 < launch.default_timeout() <= 3600
+    monkeypatch.setenv("DVO_LAUNCH_TIMEOUT", "42")
+    assert launch.default_timeout() == 42.0
+    assert launch.pg_timeout().total_seconds() > 0
+
+
 def test_world_size_mismatch_is_an_error():
     assert launch.check_world(2, env={"RANK": "1", "LOCAL_RANK": "1", "WORLD_SIZE": "2"}) == 2
     with pytest.raises(launch.LaunchError):

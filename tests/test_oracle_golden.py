@@ -368,3 +368,22 @@ def test_bilinear_replacement_equals_the_reference_function_where_it_is_defined(
         got = O.bilinear(g["image_" + name], uv[:, 0], uv[:, 1])
         assert got.dtype == np.float32 and not np.isnan(got).any()
         assert np.array_equal(got.reshape(-1, 1), g["out_" + name])
+
+
+# ---------------------------------------------------------------------------------------------
+# the reference CLI's colour data flow (src/test_dvo.py:183 + core/base_dense_visual_odometry.py:58)
+# ---------------------------------------------------------------------------------------------
+def test_reference_cli_colour_data_flow(frames, golden_dir):
+    """cli_compat.npz: fixture frames 1, 2 as the reference's CLI hands them to step() (RGB order into BGR2GRAY) and what its
+    step() then estimates.  The oracle's gray conversion of the swapped-channel image and its solve on those planes reproduce
+    both; the correct BGR order gives a (slightly) different gray plane — which is why the switch exists."""
+    c = np.load(golden_dir / "cli_compat.npz")
+    for k in (1, 2):
+        assert np.array_equal(O.bgr2gray(c["rgb_%d" % k]), c["gray_cli_%d" % k])
+    assert np.array_equal(O.bgr2gray(np.ascontiguousarray(c["rgb_1"][..., ::-1])), frames["gray"][0])      # true BGR order
+    assert not np.array_equal(c["gray_cli_1"], frames["gray"][0])
+    d = [c["depth_1"].copy(), c["depth_2"].copy()]
+    for a in d:
+        a[(a * frames["depth_scale"]) > 5.0] = 0                                   # base_dense_visual_odometry.py:59
+    est = O.gauss_newton(c["gray_cli_1"], d[0], c["gray_cli_2"], frames["K"], frames["depth_scale"], levels=4, max_iterations=10)
+    np.testing.assert_allclose(est.log(), c["tf_xi"], rtol=0, atol=2e-7)

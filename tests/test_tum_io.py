@@ -39,6 +39,10 @@ def test_association_follows_reference_rules(tmp_path):
     assert seq.gt_T_wc.shape == (3, 4, 4) and abs(seq.gt_T_wc[1, 0, 3] - 0.1 * 17) < 1e-6
     bgr, depth = tum.read_frame(seq.rgb_paths[0], seq.depth_paths[0])
     assert bgr.shape == (6, 8, 3) and bgr.dtype == np.uint8 and depth.dtype == np.uint16 and depth.shape == (6, 8)
+    rgb, _ = tum.read_frame(seq.rgb_paths[0], seq.depth_paths[0], channel_order="rgb")       # the reference CLI's array
+    assert np.array_equal(rgb[..., ::-1], bgr) and rgb.flags["C_CONTIGUOUS"]
+    with pytest.raises(ValueError):
+        tum.read_frame(seq.rgb_paths[0], seq.depth_paths[0], channel_order="gbr")
     assert len(tum.load_tum_sequence(tmp_path, size=2)) == 2
     with pytest.raises(FileNotFoundError):
         tum.load_tum_sequence(tmp_path / "rgb")

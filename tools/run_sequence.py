@@ -47,6 +47,11 @@ def parse_args():
                                                            "also for --fixture / --synthetic (B = G = R)")
     ap.add_argument("--camera", type=Path, default=None, help="camera_intrinsics.yaml (TUM mode; default fr1)")
     ap.add_argument("--out", type=Path, default=ROOT / "gpurun_out" / "sequence")
+    ap.add_argument("--reference-cli-compat", action="store_true",
+                    help="reproduce the data flow of the reference's own CLI for like-for-like comparisons with its runs: colour frames "
+                         "reach the BGR2GRAY ingest in RGB order (src/test_dvo.py:183 + core/base_dense_visual_odometry.py:58: red / blue "
+                         "weights swapped) and the TUM trajectory is stamped with the associated GROUND-TRUTH timestamps (:203, :337-345) "
+                         "instead of the frame stamps.  With --fixture: the two colour fixture frames of tests/golden/cli_compat.npz")
     ap.add_argument("--gpus", type=int, default=1, help="shard the pairs of the sequence over this many GPUs (one process each)")
     ap.add_argument("--spawn", action="store_true", help="go through the rank launcher even for --gpus 1")
     return ap.parse_args()
@@ -67,6 +72,7 @@ def main():
     from dvo_amd.batch import StreamedAligner
 
     rank, local_rank, world = launch.rank_env()
+    launch.mark_rank("started")
     use_dist = launch.started_by_launcher() or os.environ.get("DVO_FORCE_DIST") == "1"
     if use_dist:
         try:
@@ -82,7 +88,20 @@ def main():
 
     # -- the sequence: (n_total, frame source for a range, ground truth, intrinsics, stamps) ------------------------
     colour = args.colour
-    if args.fixture:
+    compat = args.reference_cli_compat
+    if compat and args.synthetic:
+        raise SystemExit("run_sequence.py: --reference-cli-compat applies to colour images on disk (--tum-dir, --fixture)")
+    if args.fixture and compat:
+        # the reference CLI's own data flow on the fixture's colour frames 1, 2 (oracle/refrun/make_golden.py: cli_compat_case)
+        c = np.load(ROOT / "tests" / "golden" / "cli_compat.npz")
+        f = np.load(ROOT / "tests" / "golden" / "frames.npz")
+        rgbs, depths, gt = [c["rgb_1"], c["rgb_2"]], [c["depth_1"], c["depth_2"]], f["gt_T"][:2]
+        K, scale, stamps, kind, colour, n_total = f["intrinsics"], float(f["depth_scale"]), np.arange(2, dtype=float), "TEST", True, 2
+
+        def source(lo, hi):
+            for k in range(lo, hi):
+                yield rgbs[k], depths[k]                 # RGB order into the BGR ingest, as the reference CLI does
+    elif args.fixture:
         f = np.load(ROOT / "tests" / "golden" / "frames.npz")
         grays, depths, gt = f["gray"], f["depth"], f["gt_T"]
         K, scale, stamps, kind = f["intrinsics"], float(f["depth_scale"]), np.arange(len(grays), dtype=float), "TEST"
@@ -106,10 +125,13 @@ def main():
         K = cam.intrinsics[:3, :3] if cam else synthetic.TUM_FR1_K
         scale = cam.depth_scale if cam else synthetic.DEPTH_SCALE
         gt, stamps, kind, colour, n_total = seq.gt_T_wc, seq.timestamps, "TUM", True, len(seq)
+        if compat and seq.gt_timestamps is not None:
+            stamps = seq.gt_timestamps               # src/test_dvo.py:203: the txt carries the ground-truth stamps
+        order = "rgb" if compat else "bgr"
 
         def source(lo, hi):                          # decoded lazily, by the decoder pool, for this rank's range only
             for k in range(lo, hi):
-                yield (lambda k=k: tum.read_frame(seq.rgb_paths[k], seq.depth_paths[k]))
+                yield (lambda k=k: tum.read_frame(seq.rgb_paths[k], seq.depth_paths[k], order))
 
     def make_aligner(h, w, window):
         return StreamedAligner(K, scale, w, h, args.levels, max_pairs=window, n_streams=args.streams, device=local_rank,
@@ -126,26 +148,30 @@ def main():
     if use_dist:
         import torch
         import torch.distributed as dist
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank), timeout=launch.pg_timeout())
         if dist.get_world_size() != world:
             raise SystemExit("run_sequence.py: %d ranks joined, %d expected" % (dist.get_world_size(), world))
         T_rel, iters = sequence.gather_shards(T_rel, iters, n_total, device="cuda")
         dist.barrier()
         if rank != 0:
             dist.destroy_process_group()
+            launch.mark_rank("done")
             return
 
     extra = {"frames": int(n_total), "n_gpus": int(world), "seconds_decode_upload_and_solve": res["seconds"],
              "seconds_decode_thread": decode_s,
              "frame_pairs_per_s_including_decode_and_upload": (n_local / res["seconds"]) * world if res["seconds"] > 0 else None,
-             "gn_iterations_mean": float(np.mean(iters)) if len(iters) else 0.0, "input": "bgr" if colour else "gray",
-             "variant": args.variant, "max_iterations_per_level": args.iterations, "level_iterations": args.level_iterations}
+             "gn_iterations_mean": float(np.mean(iters)) if len(iters) else 0.0,
+             "input": ("rgb fed as bgr (reference CLI)" if compat else "bgr") if colour else "gray",
+             "variant": args.variant, "max_iterations_per_level": args.iterations, "level_iterations": args.level_iterations,
+             "reference_cli_compat": bool(compat)}
     report, traj = sequence.build_report(kind, T_rel, gt[0] if gt is not None else None, gt, stamps, extra)
     sequence.write_report(args.out, report, traj)
     print(json.dumps({k: v for k, v in report.items() if not isinstance(v, list)}))
     if use_dist:
         import torch.distributed as dist
         dist.destroy_process_group()
+    launch.mark_rank("done")
 
 
 if __name__ == "__main__":
