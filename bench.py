@@ -14,7 +14,14 @@ the per-pair pose records are all-gathered over RCCL inside the timed region.
 The JSON line also carries
   roofline     — the dominant kernel (level-0 k_reduce): algorithmic bytes of SURVEY 8d (2P + 10V per pair
                  per launch, with the measured V) / its average duration from HIP events on its own stream
-  cpu_baseline — the NumPy oracle (a port of the reference CPU path) timed on this host on a bounded sample.
+  cpu_baseline — the NumPy oracle (a port of the reference CPU path) timed on this host on a bounded sample
+and, at N = 1 on the default workload, outside the `value` region (BASELINE.json north_star's report):
+  config3             — configs[2]: 1280x960, 5 levels, Huber: frame-pairs/s and its own level-0 roofline object
+  pcie_inclusive      — the same solve fed from page-locked host memory (gray and colour, 2 / 4 slices)
+  student_t_reference — the reference's own robust weighting (use_weighter=True) on the metric's workload
+  production_mode     — the build's Gauss-Newton mode (build-defined)
+Everything under a key named `recorded_..._not_measured_in_this_run` (and `roofline.traffic`) is a committed counter
+reading with the commit it was taken at (profiles/recorded_counters.json, profiles/pmc_traffic.json), not a product of this run.
 """
 import argparse
 import json
@@ -63,6 +70,8 @@ def parse_args():
     ap.add_argument("--spawn", action="store_true",
                     help="start the ranks through the launcher even for --gpus 1 (rehearses the multi-GPU entry on one GPU)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="skip the legs beside the metric (production mode, Student-t, PCIe-inclusive, 1280x960 config 3, fixture ATE): A/B scripts")
     ap.add_argument("--cpu-pairs", type=int, default=16, help="frame pairs of the CPU baseline sample (~0.35 s each on one thread)")
     return ap.parse_args()
 
@@ -158,6 +167,147 @@ def cpu_baseline(stream_np, levels, iterations, n_pairs):
     except Exception as e:                                            # pragma: no cover
         out["w1280x960"] = {"error": repr(e)}
     return out
+
+
+RECORDED_FILE = ROOT / "profiles" / "recorded_counters.json"   # counter readings taken OUTSIDE this run (rocprofv3 PMC), with their commit
+
+
+def recorded_counters():
+    """Counter-derived facts about the dominant kernel that cannot be measured inside this process (rocprofv3 PMC passes; accuracy
+    runs): read from profiles/recorded_counters.json together with the commit / date they were taken at.  Reported under keys
+    that say so; nothing in them is produced by this run."""
+    try:
+        return json.loads(RECORDED_FILE.read_text())
+    except Exception:
+        return None
+
+
+def roofline_leg(part, gray_ptr, depth_ptr, n_pairs, steps):
+    """Every reduction launch of `steps` full solves on ONE stream bracketed by HIP events on that stream (each timed launch has
+    the GPU to itself, like a rocprofv3 kernel trace) -> (launches per level, ms per level)."""
+    part.ctx.profile_enable(True)
+    part.ctx.profile_read(reset=True)
+    for _ in range(steps):
+        part.ingest_device(gray_ptr, depth_ptr, n_pairs + 1)
+        part.solve_enqueue(n_pairs + 1)
+        part.solve_fetch(n_pairs + 1)
+    launches, ms = part.ctx.profile_read(reset=True)
+    part.ctx.profile_enable(False)
+    return launches, ms
+
+
+def timed_steps(fn, sync, steps, warmup=1):
+    for _ in range(warmup):
+        fn()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        out = fn()
+    sync()
+    return (time.perf_counter() - t0) / steps, out
+
+
+def leg_student_t(st, gray, depth, B, W, H, L, iterations, streams, device, steps):
+    """The reference's own robust mode (use_weighter=True: TDistributionWeighter, weighter/t_weighter.py:21-47) on the metric's
+    workload: same stream, same batch, device solve."""
+    import torch
+    from dvo_amd.batch import StreamedAligner
+    al = StreamedAligner(st["K"], st["depth_scale"], W, H, L, max_pairs=B, n_streams=streams, device=device,
+                         max_iterations=iterations, weighting="student_t_reference")
+    try:
+        def sync():
+            al.synchronize()
+            torch.cuda.synchronize()
+        dt, res = timed_steps(lambda: al.align_device(gray.data_ptr(), depth.data_ptr(), B + 1), sync, steps)
+    finally:
+        al.close()
+    return {"frame_pairs_per_s": B / dt, "ms_per_step": 1e3 * dt, "steps": steps, "batch_pairs": B,
+            "weighting": "student_t_reference (TDistributionWeighter as written, summing quirk included)",
+            "gn_iterations_per_pair": float(res["iters"].sum()) / B}
+
+
+def leg_pcie(st, gray, depth, B, W, H, L, iterations, device, steps):
+    """PCIe-inclusive rate (never `value`): the same frames start in page-locked HOST memory; a step = batched upload + pyramid
+    build + full solve, slices of the batch overlapping their copies with each other's kernels (dvo_set_upload_peer)."""
+    import numpy as np
+    import torch
+    from dvo_amd import _cabi
+    from dvo_amd.batch import StreamedAligner
+    n = B + 1
+    gp = _cabi.pinned_array((n, H, W), np.uint8)
+    dp = _cabi.pinned_array((n, H, W), np.uint16)
+    gp[...] = gray[:n].cpu().numpy()
+    dp[...] = depth[:n].cpu().numpy().view(np.uint16)
+    bgr = _cabi.pinned_array((n, H, W, 3), np.uint8)
+    bgr[...] = gp[:, :, :, None]
+    out = {"batch_pairs": B, "host_memory": "page-locked", "steps": steps}
+    for slices in (2, 4):
+        al = StreamedAligner(st["K"], st["depth_scale"], W, H, L, max_pairs=B, n_streams=slices, device=device, max_iterations=iterations)
+        try:
+            def sync():
+                al.synchronize()
+                torch.cuda.synchronize()
+            dt, _ = timed_steps(lambda: al.align_host(gp, dp), sync, steps)
+            out["gray_%d_slices" % slices] = {"frame_pairs_per_s": B / dt, "link_GBs": n * W * H * 3 / dt / 1e9}
+            dt, _ = timed_steps(lambda: al.align_host_bgr(bgr, dp), sync, steps)
+            out["colour_%d_slices" % slices] = {"frame_pairs_per_s": B / dt, "link_GBs": n * W * H * 5 / dt / 1e9}
+        finally:
+            al.close()
+    del gp, dp, bgr
+    return out
+
+
+def leg_config3(device, iterations, streams, steps):
+    """BASELINE.json configs[2]: synthetic 1280x960 RGB-D stream, 5-level pyramid, Huber weighting, 1 GPU.  The largest batch of
+    512 / 256 / 128 pairs that fits; 129 rendered frames played forwards and backwards (every pair is two consecutive renders)."""
+    import numpy as np
+    import torch
+    from dvo_amd import synthetic
+    from dvo_amd.batch import StreamedAligner
+    W, H, L = 1280, 960, 5
+    n_render = 129
+    st = synthetic.make_stream(n_render, W, H, seed=1234, device="cuda", as_torch=True)
+    last_err = None
+    for B in (512, 256, 128):
+        al = None
+        try:
+            idx = np.arange(B + 1) % (2 * (n_render - 1))
+            idx = np.where(idx < n_render, idx, 2 * (n_render - 1) - idx)              # 0..128,127..0,1..: consecutive renders only
+            sel = torch.as_tensor(idx, device="cuda")
+            gray = st["gray"].index_select(0, sel).contiguous()
+            depth = st["depth"].index_select(0, sel).contiguous()
+            al = StreamedAligner(st["K"], st["depth_scale"], W, H, L, max_pairs=B, n_streams=streams, device=device,
+                                 max_iterations=iterations, weighting="huber")
+
+            def sync():
+                al.synchronize()
+                torch.cuda.synchronize()
+            dt, res = timed_steps(lambda: al.align_device(gray.data_ptr(), depth.data_ptr(), B + 1), sync, steps)
+            part = al.parts[0]
+            npr = min(B, part.max_pairs)
+            launches, ms = roofline_leg(part, gray.data_ptr(), depth.data_ptr(), npr, 2)
+            valid_l0 = float((depth[:npr] != 0).sum().item()) / npr
+            alg = (2.0 * W * H + 10.0 * valid_l0) * npr
+            avg_ms = ms[0] / max(launches[0], 1)
+            out = {"workload": "synthetic 1280x960 RGB-D stream, 5-level pyramid, %d GN iterations/level, Huber weighting (build-defined: "
+                               "the reference has no Huber), %d frame pairs per step in %d streams, ingest + device solve timed" % (iterations, B, streams),
+                   "frame_pairs_per_s": B / dt, "ms_per_step": 1e3 * dt, "steps": steps, "batch_pairs": B,
+                   "gn_iterations_per_pair": float(res["iters"].sum()) / B,
+                   "roofline": {"kernel": "k_reduce<V1,huber> level 0 (1280x960), %d pairs per launch" % npr, "avg_launch_us": 1e3 * avg_ms,
+                                "launches_timed": int(launches[0]), "algorithmic_bytes_per_launch": alg,
+                                "achieved": alg / (avg_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                "frac": alg / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "valid_fraction_level0": valid_l0 / (W * H)}}
+            al.close()
+            return out
+        except Exception as e:                                   # out of memory at this batch: try the next smaller one
+            last_err = repr(e)
+            if al is not None:
+                try:
+                    al.close()
+                except Exception:
+                    pass
+            torch.cuda.empty_cache()
+    return {"error": last_err}
 
 
 def fixture_ate(device):
@@ -271,6 +421,7 @@ def main():
         res = step()
     fence()
     elapsed = time.perf_counter() - t0
+    elapsed_rank = elapsed
     if use_dist:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -278,23 +429,27 @@ def main():
     iters_total = int(res["iters"].sum())
 
     # --- roofline leg: same steps again with every reduction launch bracketed by HIP events ----------------
-    # (run on ONE stream so that each timed launch has the GPU to itself, like the rocprofv3 kernel trace)
+    # (run on ONE stream so that each timed launch has the GPU to itself, like the rocprofv3 kernel trace; every rank does it,
+    # so that a multi-GPU record shows each rank's kernel time next to its step time)
     prof = al.parts[0]
     npr = min(B, prof.max_pairs)
-    prof.ctx.profile_enable(True)
-    prof.ctx.profile_read(reset=True)
-    prof_steps = max(1, min(args.steps, 5))
-    for _ in range(prof_steps):
-        prof.ingest_device(gray.data_ptr(), depth.data_ptr(), npr + 1)
-        prof.solve_enqueue(npr + 1)
-        prof.solve_fetch(npr + 1)
-    launches, ms = prof.ctx.profile_read(reset=True)
-    prof.ctx.profile_enable(False)
+    launches, ms = roofline_leg(prof, gray.data_ptr(), depth.data_ptr(), npr, max(1, min(args.steps, 5)))
+    per_rank = None
+    if use_dist:
+        mine = torch.tensor([1e3 * elapsed_rank / args.steps, 1e3 * ms[0] / max(launches[0], 1)], dtype=torch.float64, device="cuda")
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        allr = torch.stack(allr).cpu().numpy()
+        per_rank = {"ms_per_step": [float(v) for v in allr[:, 0]], "level0_avg_launch_us": [float(v) for v in allr[:, 1]],
+                    "ms_per_step_min": float(allr[:, 0].min()), "ms_per_step_max": float(allr[:, 0].max())}
 
     # --- the build's own production mode beside the metric (N = 1, default workload only): true Gauss-Newton steps on the same
     # kernel (DVO_VARIANT_GN), 1 iteration at the finest level and 2 at the others.  Reported under "production_mode"; never `value`.
     gn_mode = None
-    if world == 1 and args.variant == "v1" and args.weighting == "none" and not args.level_iterations:
+    extras = (world == 1 and rank == 0 and not args.no_extras and args.variant == "v1" and args.weighting == "none"
+              and not args.level_iterations and (W, H, L) == (640, 480, 4))
+    rec = recorded_counters() or {}
+    if extras:
         from dvo_amd import _cabi
         sched = [1] + [2] * (L - 1)                       # finest level first (tools/exp_gn_schedule.sh)
         for a in al.parts:
@@ -311,8 +466,7 @@ def main():
         gn_mode = {"variant": "gn (DVO_VARIANT_GN: V1 with the Sobel response normalised and J_w at the warped point; build-defined, "
                               "not a reference behaviour)", "gn_iterations_per_level_finest_first": sched, "frame_pairs_per_s": B * gn_steps / tg,
                    "ms_per_step": 1e3 * tg / gn_steps, "steps": gn_steps,
-                   "accuracy_note": "rendered sequence with exact ground truth: ATE 0.21 mm against 1.06 mm for the metric's V1 at 10 "
-                                    "iterations per level (DESIGN.md section 6)"}
+                   "recorded_accuracy_not_measured_in_this_run": rec.get("production_mode_accuracy")}
         for a in al.parts:
             a.variant, a.max_iterations = _cabi.VARIANT_V1, args.iterations
             a.ctx.set_level_iterations(None)
@@ -348,20 +502,42 @@ def main():
                        "gn_iterations_per_s": world * iters_total * args.steps / elapsed,
                        "pose_gather_ms_per_step": (1e3 * gather_s[0] / args.steps) if use_dist else None,
                        "parallelism": "1 independent stream per GPU, RCCL all-gather of pose records"},
-            "roofline": {"bound": "hbm", "limiter_measured": "VALU issue (145 instructions per point-wave at 3.2 cycles each, clock 2.1 GHz in-kernel: 0.62 of the 2-cycle issue roofline, 0.72 with the instruction mix priced), beside a texture addresser 61 % busy (3.35 vector-memory instructions per point-wave) and an HBM stream (`traffic` / launch time) at 0.53 of peak = 0.67 of the achievable rate with no wasted re-reads (DESIGN.md section 5)", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS,
+                         # `traffic`: HBM bytes per launch from rocprofv3 PMC counters.  PMC counters cannot be read from inside this
+                         # process: the value is the committed reading of the same launch shape (profiles/pmc_traffic.json), taken
+                         # at `traffic_recorded_at`; null when no reading of this shape exists
                          "traffic": (recorded_traffic(npr, W, H) or {}).get("hbm_bytes_per_launch"),
+                         "traffic_recorded_at": (recorded_traffic(npr, W, H) or {}).get("commit"),
                          "traffic_source": (recorded_traffic(npr, W, H) or {}).get("source"),
                          "kernel": "k_reduce<V1,finest> level 0 (%dx%d), %d pairs per launch" % (W, H, npr),
                          "avg_launch_us": 1e3 * avg_ms, "launches_timed": int(launches[0]),
                          "algorithmic_bytes_per_launch": alg_bytes,
                          "layout_bytes_per_launch": layout_bytes,
                          "achieved_layout_GBs": layout_bytes / (avg_ms * 1e-3) / 1e9,
-                         "valid_fraction_level0": valid_l0 / P0, "per_level": per_level},
+                         "valid_fraction_level0": valid_l0 / P0, "per_level": per_level,
+                         "recorded_limiter_not_measured_in_this_run": rec.get("level0_reduction")},
         }
+        if per_rank is not None:
+            out["per_rank"] = per_rank
         if gn_mode is not None:
             out["production_mode"] = gn_mode
-        if world == 1:
+    al.close()
+    al = None
+    if rank == 0:
+        if extras:
+            # the rest of what north_star asks to be reported, on the driver's clock, outside the `value` region and bounded in time
+            # (each leg builds and frees its own contexts; a leg that fails reports its error instead of taking the line down)
+            es = max(2, min(args.steps, 10))
+            for name, fn in (("student_t_reference", lambda: leg_student_t(st, gray, depth, B, W, H, L, args.iterations, args.streams, local_rank, es)),
+                             ("pcie_inclusive", lambda: leg_pcie(st, gray, depth, min(B, 512), W, H, L, args.iterations, local_rank, max(2, min(es, 5)))),
+                             ("config3", lambda: leg_config3(local_rank, args.iterations, args.streams, es))):
+                try:
+                    out[name] = fn()
+                except Exception as e:                                         # pragma: no cover
+                    out[name] = {"error": repr(e)}
+                torch.cuda.empty_cache()
+        if world == 1 and not args.no_extras:
             out["accuracy"] = fixture_ate(local_rank)
         if not args.no_cpu_baseline and world == 1:            # CPU baseline: rank 0 at N=1 only
             cpu_frames = min(args.cpu_pairs + 1, n_frames)
@@ -370,7 +546,6 @@ def main():
                      "K": st["K"], "depth_scale": st["depth_scale"]}
             out["cpu_baseline"] = cpu_baseline(st_np, L, args.iterations, args.cpu_pairs)
         print(json.dumps(out))
-    al.close()
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()

@@ -4,7 +4,7 @@
 mkdir -p gpurun_out
 for round in 1 2; do
   for lib in "$@"; do
-    DVO_HIP_LIB=$PWD/$lib python bench.py --steps 10 --warmup 2 --no-cpu-baseline 2>/dev/null | python -c "
+    DVO_HIP_LIB=$PWD/$lib python bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-extras 2>/dev/null | python -c "
 import sys, json
 d = json.loads(sys.stdin.read().strip().splitlines()[-1])
 r = d['roofline']

@@ -3,7 +3,7 @@
 for cfg in "default default" "1024 20" "1024 38" "1024 75" "1024 150" "512 75"; do
   set -- $cfg
   if [ "$1" = default ]; then unset DVO_TARGET_BLOCKS DVO_MAX_GROUPS; else export DVO_TARGET_BLOCKS=$1 DVO_MAX_GROUPS=$2; fi
-  python bench.py --steps 10 --warmup 2 --no-cpu-baseline 2>/dev/null | python -c "
+  python bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-extras 2>/dev/null | python -c "
 import sys, json
 d = json.loads(sys.stdin.read().strip().splitlines()[-1])
 r = d['roofline']

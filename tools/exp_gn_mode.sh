@@ -16,7 +16,7 @@ print('synthetic variant $1 iterations $2: ATE %.3f mm  RPE %.3f mm  GN iteratio
 done
 for cfg in "v1 10" "gn 10" "gn 3"; do
   set -- $cfg
-  python bench.py --variant $1 --iterations $2 --steps 10 --warmup 2 --no-cpu-baseline 2>/dev/null | python -c "
+  python bench.py --variant $1 --iterations $2 --steps 10 --warmup 2 --no-cpu-baseline --no-extras 2>/dev/null | python -c "
 import sys, json
 d = json.loads(sys.stdin.read().strip().splitlines()[-1])
 print('bench     variant $1 iterations $2: %.0f frame-pairs/s  %.2f ms/step  L0 %.1f us' % (d['value'], d['ms_per_step'], d['roofline']['avg_launch_us']))

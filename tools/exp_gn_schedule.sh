@@ -12,7 +12,7 @@ import sys, json
 d = json.loads(sys.stdin.read().strip().splitlines()[-1])
 print('gn schedule %-9s fixture : ATE %.3f mm  RPE %.4f mm' % ('$s', 1e3 * d['ate_rmse_m'], 1e3 * d['rpe_trans_rmse_m']))
 " | tee -a $O/summary.txt
-  python bench.py --variant gn --level-iterations $s --steps 10 --warmup 2 --no-cpu-baseline 2>/dev/null | python -c "
+  python bench.py --variant gn --level-iterations $s --steps 10 --warmup 2 --no-cpu-baseline --no-extras 2>/dev/null | python -c "
 import sys, json
 d = json.loads(sys.stdin.read().strip().splitlines()[-1])
 print('gn schedule %-9s bench   : %.0f frame-pairs/s  %.2f ms/step' % ('$s', d['value'], d['ms_per_step']))

@@ -3,7 +3,7 @@
 for q in default 8 16 2; do
   if [ "$q" = default ]; then unset GPU_MAX_HW_QUEUES; else export GPU_MAX_HW_QUEUES=$q; fi
   for st in 4 8; do
-  python bench.py --steps 10 --warmup 2 --streams $st --no-cpu-baseline 2>/dev/null | python -c "
+  python bench.py --steps 10 --warmup 2 --streams $st --no-cpu-baseline --no-extras 2>/dev/null | python -c "
 import sys, json
 d = json.loads(sys.stdin.read().strip().splitlines()[-1])
 r = d['roofline']
@@ -15,7 +15,7 @@ done
 for cfg in "default 4 1024" "default 2 1024" "default 3 1023" "8 3 1023" "8 2 1024" "default 6 1020" "default 5 1020"; do
   set -- $cfg
   if [ "$1" = default ]; then unset GPU_MAX_HW_QUEUES; else export GPU_MAX_HW_QUEUES=$1; fi
-  python bench.py --steps 10 --warmup 2 --streams $2 --batch $3 --no-cpu-baseline 2>/dev/null | python -c "
+  python bench.py --steps 10 --warmup 2 --streams $2 --batch $3 --no-cpu-baseline --no-extras 2>/dev/null | python -c "
 import sys, json
 d = json.loads(sys.stdin.read().strip().splitlines()[-1])
 r = d['roofline']

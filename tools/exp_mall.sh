@@ -3,7 +3,7 @@
 # per-iteration data (~2.95 MB per VGA pair) do / do not fit.
 for cfg in "1024 4" "64 1" "32 1" "128 2" "64 2" "256 1" "128 1"; do
   set -- $cfg
-  python bench.py --batch $1 --streams $2 --steps 20 --warmup 3 --no-cpu-baseline 2>/dev/null | python -c "
+  python bench.py --batch $1 --streams $2 --steps 20 --warmup 3 --no-cpu-baseline --no-extras 2>/dev/null | python -c "
 import sys, json
 d = json.loads(sys.stdin.read().strip().splitlines()[-1])
 r = d['roofline']

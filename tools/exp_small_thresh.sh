@@ -3,7 +3,7 @@
 for cfg in "default default" "76800 1024" "76800 512" "76800 256" "19200 512" "19200 1024" "default default"; do
   set -- $cfg
   if [ "$1" = default ]; then unset DVO_SMALL_MAX_PIX DVO_SMALL_THREADS; else export DVO_SMALL_MAX_PIX=$1 DVO_SMALL_THREADS=$2; fi
-  python bench.py --steps 10 --warmup 2 --no-cpu-baseline 2>/dev/null | python -c "
+  python bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-extras 2>/dev/null | python -c "
 import sys, json
 d = json.loads(sys.stdin.read().strip().splitlines()[-1])
 r = d['roofline']

@@ -3,7 +3,7 @@
 export TMPDIR=/tmp
 OUT=gpurun_out/kstats_ingest
 rm -rf $OUT; mkdir -p $OUT
-rocprofv3 --kernel-trace --kernel-include-regex "k_batch|k_list|k_ingest" --output-format csv -d $OUT/trace -- python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline "$@" > $OUT/trace.log 2>&1
+rocprofv3 --kernel-trace --kernel-include-regex "k_batch|k_list|k_ingest" --output-format csv -d $OUT/trace -- python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-extras "$@" > $OUT/trace.log 2>&1
 f=$(find $OUT/trace -name "*kernel_trace.csv" | head -1)
 python3 - "$f" <<'PY' | tee $OUT/summary.txt
 import csv, sys, collections

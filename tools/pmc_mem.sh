@@ -7,7 +7,7 @@ TAG=$1; LIB=$2
 OUT=gpurun_out/pmc_mem_$TAG
 rm -rf $OUT; mkdir -p $OUT
 [ -n "$LIB" ] && export DVO_HIP_LIB=$PWD/$LIB
-ARGS="bench.py --steps 3 --warmup 1 --no-cpu-baseline"
+ARGS="bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extras"
 pass() {   # name counters...
   local name=$1; shift
   if [ -n "$PASSES" ] && ! echo " $PASSES " | grep -q " $name "; then return; fi

@@ -5,7 +5,7 @@ set -o pipefail
 export TMPDIR=/tmp
 OUT=gpurun_out/prof
 rm -rf $OUT; mkdir -p $OUT
-ARGS="bench.py --steps 5 --warmup 1 --no-cpu-baseline $@"
+ARGS="bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-extras $@"
 echo "command: python3 $ARGS" > $OUT/command.txt
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $ARGS > $OUT/trace.log 2>&1
 rocprofv3 --kernel-include-regex "k_reduce" --pmc FETCH_SIZE TCC_HIT_sum --output-format csv -d $OUT/pmc_fetch -- python3 $ARGS > $OUT/pmc_fetch.log 2>&1

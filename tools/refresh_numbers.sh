@@ -3,14 +3,14 @@
 # single-GPU rehearsal of the multi-rank path.  Outputs under gpurun_out/refresh/.
 O=gpurun_out/refresh; rm -rf $O; mkdir -p $O
 python bench.py > $O/bench_default.json 2> $O/bench_default.err
-python bench.py --width 1280 --height 960 --levels 5 --weighting huber --batch 128 --steps 10 --no-cpu-baseline > $O/bench_1280_huber.json 2>> $O/err.log
-python bench.py --weighting student_t_reference --batch 256 --steps 10 --no-cpu-baseline > $O/bench_student_t.json 2>> $O/err.log
-python bench.py --weighting huber --steps 10 --no-cpu-baseline > $O/bench_huber_vga.json 2>> $O/err.log
-python bench.py --weighting student_t --batch 256 --steps 10 --no-cpu-baseline > $O/bench_student_t_mean.json 2>> $O/err.log
-python bench.py --variant v2 --steps 10 --no-cpu-baseline > $O/bench_v2.json 2>> $O/err.log
-python bench.py --variant v3 --steps 10 --no-cpu-baseline > $O/bench_v3.json 2>> $O/err.log
-python bench.py --width 1280 --height 960 --levels 5 --batch 128 --steps 10 --no-cpu-baseline > $O/bench_1280_none.json 2>> $O/err.log
-python bench.py --gpus 1 --spawn --steps 10 --no-cpu-baseline 2>> $O/err.log | grep "^{" > $O/bench_dist1.json
+python bench.py --width 1280 --height 960 --levels 5 --weighting huber --batch 128 --steps 10 --no-cpu-baseline --no-extras > $O/bench_1280_huber.json 2>> $O/err.log
+python bench.py --weighting student_t_reference --batch 256 --steps 10 --no-cpu-baseline --no-extras > $O/bench_student_t.json 2>> $O/err.log
+python bench.py --weighting huber --steps 10 --no-cpu-baseline --no-extras > $O/bench_huber_vga.json 2>> $O/err.log
+python bench.py --weighting student_t --batch 256 --steps 10 --no-cpu-baseline --no-extras > $O/bench_student_t_mean.json 2>> $O/err.log
+python bench.py --variant v2 --steps 10 --no-cpu-baseline --no-extras > $O/bench_v2.json 2>> $O/err.log
+python bench.py --variant v3 --steps 10 --no-cpu-baseline --no-extras > $O/bench_v3.json 2>> $O/err.log
+python bench.py --width 1280 --height 960 --levels 5 --batch 128 --steps 10 --no-cpu-baseline --no-extras > $O/bench_1280_none.json 2>> $O/err.log
+python bench.py --gpus 1 --spawn --steps 10 --no-cpu-baseline --no-extras 2>> $O/err.log | grep "^{" > $O/bench_dist1.json
 python tools/latency_step.py > $O/latency.txt 2>> $O/err.log
 python tools/exp_pcie.py > $O/pcie.txt 2>> $O/err.log
 python tools/run_sequence.py --fixture --out $O/seq_fixture > $O/seq_fixture.txt 2>> $O/err.log
