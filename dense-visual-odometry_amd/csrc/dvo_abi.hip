@@ -38,7 +38,8 @@ struct HostStage {          // pinned staging for the small per-call arrays
 }  // namespace
 
 struct SolveKey {
-    int n_pairs, w, h, levels, max_iterations, max_increased, variant, weight_mode, has_init, trace_cap, has_last, pad;
+    int n_pairs, w, h, levels, max_iterations, max_increased, variant, weight_mode, has_init, trace_cap, has_last;
+    int st_exact;                       // Student-t of the reference: 1 = the three-pass form at every level (no moment form)
     double tolerance, weight_param, inv_sigma;
     const void* trace;
     const void* stream;
@@ -88,6 +89,13 @@ struct dvo_ctx {
     int* d_irls_done = nullptr;          // Student-t device solve with control launches: per pair, IRLS converged for this iteration
     double* d_scale1 = nullptr;          // Student-t device solve: per-workgroup sums of the two scale passes
     double* d_scale2 = nullptr;
+    double* d_partials2 = nullptr;       // Student-t moment form: the r^2-weighted partial sums (same shape as d_partials)
+    int* d_inexact = nullptr;            // ... iterations whose expansion bound was not met (device counter) and its page-locked copy
+    int* h_inexact = nullptr;
+    bool last_moment = false;            // the solve enqueued last used the moment form (dvo_solve_batch_fetch may have to repeat it)
+    SolveKey last_key;
+    bool last_has_init = false;
+    int64_t st_fallbacks = 0;            // solves repeated with the three-pass form
     float* d_rcache = nullptr;           // Student-t device solve: residuals kept between the scale passes [max_pairs][max_w*max_h]
     uint32_t* d_exp_gradh = nullptr;     // DVO_EXP_TAPS side planes [n_slots][exp_plane_texels]: {f16 gx, f16 gy} / intensity
     uint8_t* d_exp_ipl = nullptr;
@@ -135,6 +143,7 @@ struct dvo_ctx {
         int small_max_pix = 19200;      // DVO_SMALL_MAX_PIX: levels with at most this many pixels run in the persistent per-pair
                                         // kernel k_gn_small (0: every level takes the per-iteration launches)
         int small_threads = 0;          // DVO_SMALL_THREADS: workgroup size of k_gn_small (0: chosen from the batch size)
+        bool st_exact = false;          // DVO_ST_EXACT: the reference's Student-t always as its three passes (no moment form)
         int exp_taps = 0;               // DVO_EXP_TAPS=1..4: dvo_normal_equations (V1, unweighted) runs an experimental tap
                                         // formulation of the reduction (dvo_exp_taps.inc; tools/exp_taps.py); never the solve path
     } knobs;
@@ -314,6 +323,8 @@ int fill_reduce_params(dvo_ctx* ctx, int level, int n_pairs, int w, int h, DvoRe
     p->active = nullptr;
     p->finest = (level == 0) ? (ctx->profiling ? 2 : 1) : 0;
     p->partials = ctx->d_partials;
+    p->partials2 = nullptr;
+    p->lambda0 = 0.04f;
     p->list_count = ctx->d_list_count;
     p->level = level;
     p->rcache = nullptr;
@@ -494,6 +505,7 @@ int dvo_create(int device, int max_w, int max_h, int max_levels, int n_slots, in
         ctx->knobs.st_solve_phases = getenv("DVO_ST_SOLVE_PHASES") != nullptr;
         ctx->knobs.no_rcache = getenv("DVO_NO_RCACHE") != nullptr;
         ctx->knobs.ingest_unfused = getenv("DVO_INGEST_UNFUSED") != nullptr;
+        ctx->knobs.st_exact = getenv("DVO_ST_EXACT") != nullptr;
         e = getenv("DVO_EXP_TAPS");
         if (e) ctx->knobs.exp_taps = atoi(e);
         e = getenv("DVO_SMALL_MAX_PIX");
@@ -526,9 +538,10 @@ void dvo_destroy(dvo_ctx* ctx)
     void* dev[] = {ctx->d_slots, ctx->d_prev, ctx->d_cur, ctx->d_T, ctx->d_Tinit, ctx->d_wparam, ctx->d_active, ctx->d_partials,
                    ctx->d_out, ctx->d_state, ctx->d_xi, ctx->d_iters, ctx->d_err, ctx->d_stage_img, ctx->d_dense, ctx->d_trace, ctx->d_frame_slots, ctx->d_prior, ctx->d_batch_stage,
                    ctx->d_list_count, ctx->d_seg_counts, ctx->d_rcache, ctx->d_scale1, ctx->d_scale2, ctx->d_irls_done,
-                   ctx->d_exp_gradh, ctx->d_exp_ipl};
+                   ctx->d_exp_gradh, ctx->d_exp_ipl, ctx->d_partials2, ctx->d_inexact};
     for (void* p : dev) if (p) (void)hipFree(p);
-    void* host[] = {ctx->hs.prev, ctx->hs.cur, ctx->hs.T, ctx->hs.wparam, ctx->hs.out, ctx->hs.xi, ctx->hs.iters, ctx->hs.err, ctx->h_frame_slots, ctx->h_prior};
+    void* host[] = {ctx->hs.prev, ctx->hs.cur, ctx->hs.T, ctx->hs.wparam, ctx->hs.out, ctx->hs.xi, ctx->hs.iters, ctx->hs.err, ctx->h_frame_slots, ctx->h_prior,
+                    ctx->h_inexact};
     for (void* p : host) if (p) (void)hipHostFree(p);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
@@ -1087,6 +1100,7 @@ static int record_solve(dvo_ctx* ctx, const SolveKey& k, const float* d_init)
     int rc;
     const double lambda0 = 1.0 / 25.0;                      // TDistributionWeighter: initial_sigma = 5 (t_weighter.py:11-15)
     HIP_TRY(ctx, hipMemsetAsync(ctx->d_irls_done, 0, (size_t)n_pairs * sizeof(int), ctx->stream));
+    if (ctx->d_inexact) HIP_TRY(ctx, hipMemsetAsync(ctx->d_inexact, 0, 4 * sizeof(int), ctx->stream));
     HIP_TRY(ctx, dvo_launch_init_state(ctx->d_state, ctx->d_T, d_init, n_pairs, lambda0,
                                        (k.inv_sigma > 0.0 && k.has_last) ? ctx->d_prior : nullptr, ctx->stream));
     // The coarsest levels (at most knobs.small_max_pix pixels each) run in ONE persistent launch, a workgroup per pair
@@ -1175,8 +1189,29 @@ static int record_solve(dvo_ctx* ctx, const SolveKey& k, const float* d_init)
         sp.trace_cap = ctx->trace_cap;
         sp.irls_done = nullptr;
         sp.phase = 0;
+        sp.partials2 = nullptr;
+        sp.inexact = nullptr;
+        sp.lambda0 = lambda0;
+        sp.predicted = 0;
+        // The reference's Student-t at the per-iteration levels: ONE pass per iteration (moment form, see student_t_moment_combine)
+        // instead of scale pass + cached scale pass + weighted pass, wherever the level is large enough for its bound to hold on
+        // ordinary images (>= 320x240); a solve whose bound fails is repeated with the three-pass form by dvo_solve_batch_fetch.
+        const bool moment_form = (weight_mode == DVO_WEIGHT_STUDENT_T) && !k.st_exact && !ctx->knobs.st_solve_phases &&
+                                 variant != DVO_VARIANT_V3 && ctx->d_partials2 != nullptr && p.g.npix >= 76800;
         HIP_TRY(ctx, dvo_launch_level_begin(ctx->d_state, ctx->d_active, ctx->d_wparam, n_pairs, weight_mode, lambda0, ctx->stream));
         for (int it = 0; it < k.level_iters[level]; ++it) {
+            if (moment_form) {
+                // first three iterations of the level: moment form (no lambda history to extrapolate from yet); later ones: weights
+                // under the lambda extrapolated from the three iterations before, cheaper by a whole second set of sums
+                p.partials2 = ctx->d_partials2;
+                p.lambda0 = (float)lambda0;
+                sp.predicted = (it > 2) ? 1 : 0;
+                HIP_TRY(ctx, launch_reduce_profiled(ctx, p, level, variant, sp.predicted ? 5 : 4, 0));
+                sp.partials2 = ctx->d_partials2;
+                sp.inexact = ctx->d_inexact;
+                HIP_TRY(ctx, dvo_launch_solve(sp, ctx->stream));
+                continue;
+            }
             if (weight_mode == DVO_WEIGHT_STUDENT_T || weight_mode == DVO_WEIGHT_STUDENT_T_MEAN) {
                 // IRLS scale passes (weighter/t_weighter.py:24-32): the first keeps the residuals of this pose, the later ones sum
                 // them again under the new lambda
@@ -1219,6 +1254,8 @@ static int record_solve(dvo_ctx* ctx, const SolveKey& k, const float* d_init)
 }
 
 
+static int enqueue_solve(dvo_ctx* ctx, const SolveKey& key, const float* d_init);
+
 int dvo_solve_batch_enqueue(dvo_ctx* ctx, int n_pairs, const int* prev_slot, const int* cur_slot, int levels,
                             int max_iterations, double tolerance, int max_increased_steps_allowed, int variant,
                             int weight_mode, double weight_param, const float* T_init)
@@ -1249,6 +1286,18 @@ int dvo_solve_batch_enqueue(dvo_ctx* ctx, int n_pairs, const int* prev_slot, con
             ctx->d_scale1 = ctx->d_scale2 = nullptr;
         }
     }
+    if (weight_mode == DVO_WEIGHT_STUDENT_T && ctx->d_partials2 == nullptr && !ctx->knobs.st_solve_phases) {
+        // moment form of the reference's Student-t: a second set of partial sums and the counter of unsafe iterations
+        if (hipMalloc((void**)&ctx->d_partials2, ctx->partials_doubles * sizeof(double)) != hipSuccess ||
+            hipMalloc((void**)&ctx->d_inexact, 4 * sizeof(int)) != hipSuccess ||
+            hipHostMalloc((void**)&ctx->h_inexact, 4 * sizeof(int)) != hipSuccess) {
+            (void)hipGetLastError();
+            if (ctx->d_partials2) (void)hipFree(ctx->d_partials2);
+            if (ctx->d_inexact) (void)hipFree(ctx->d_inexact);
+            ctx->d_partials2 = nullptr;
+            ctx->d_inexact = nullptr;                     // the three-pass form needs neither
+        }
+    }
     const float* d_init = nullptr;
     if (T_init) {
         memcpy(ctx->hs.T, T_init, (size_t)n_pairs * 12 * sizeof(float));
@@ -1269,6 +1318,17 @@ int dvo_solve_batch_enqueue(dvo_ctx* ctx, int n_pairs, const int* prev_slot, con
     key.inv_sigma = (ctx->prior_sigma > 0.0) ? 1.0 / ctx->prior_sigma : 0.0;
     key.has_last = ctx->prior_has_last ? 1 : 0;
     for (int l = 0; l < levels && l < DVO_MAX_LEVELS; ++l) key.level_iters[l] = ctx->level_iters_set ? ctx->level_iters[l] : max_iterations;
+    key.st_exact = ctx->knobs.st_exact ? 1 : 0;
+    ctx->last_key = key;
+    ctx->last_has_init = (T_init != nullptr);
+    ctx->last_moment = (weight_mode == DVO_WEIGHT_STUDENT_T) && !key.st_exact && ctx->d_partials2 != nullptr;
+    return enqueue_solve(ctx, key, d_init);
+}
+
+// the launch sequence of `key`: a cached hipGraph replay, a capture + replay, or plain launches (profiling / DVO_GRAPH=0)
+static int enqueue_solve(dvo_ctx* ctx, const SolveKey& key, const float* d_init)
+{
+    int rc;
     const bool use_graph = ctx->graphs_enabled && !ctx->profiling;
     if (use_graph) {
         for (auto& g : ctx->graphs)
@@ -1302,11 +1362,33 @@ int dvo_solve_batch_fetch(dvo_ctx* ctx, int n_pairs, float* T_out, double* xi_ou
     if (xi_out) HIP_TRY(ctx, hipMemcpyAsync(ctx->hs.xi, ctx->d_xi, (size_t)n_pairs * 6 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     if (iters_out) HIP_TRY(ctx, hipMemcpyAsync(ctx->hs.iters, ctx->d_iters, (size_t)n_pairs * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
     if (err_out) HIP_TRY(ctx, hipMemcpyAsync(ctx->hs.err, ctx->d_err, (size_t)n_pairs * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    if (ctx->last_moment) HIP_TRY(ctx, hipMemcpyAsync(ctx->h_inexact, ctx->d_inexact, 4 * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->last_moment && *ctx->h_inexact != 0) {
+        // an iteration of this batch did not meet the moment form's bound (or its IRLS would not take exactly two passes): the same
+        // solve again with the reference's passes as written (slot ids and initial poses are still in their device buffers)
+        ctx->last_moment = false;
+        ctx->st_fallbacks += 1;
+        if (getenv("DVO_ST_DEBUG"))
+            fprintf(stderr, "dvo: Student-t one-pass form rejected in %d iteration(s) (IRLS shape %d, moment bound %d, predicted bound %d): repeating with the three-pass form\n",
+                    ctx->h_inexact[0], ctx->h_inexact[1], ctx->h_inexact[2], ctx->h_inexact[3]);
+        SolveKey key = ctx->last_key;
+        key.st_exact = 1;
+        int rc = enqueue_solve(ctx, key, ctx->last_has_init ? ctx->d_Tinit : nullptr);
+        if (rc) return rc;
+        return dvo_solve_batch_fetch(ctx, n_pairs, T_out, xi_out, iters_out, err_out);
+    }
     if (T_out) memcpy(T_out, ctx->hs.T, (size_t)n_pairs * 12 * sizeof(float));
     if (xi_out) memcpy(xi_out, ctx->hs.xi, (size_t)n_pairs * 6 * sizeof(double));
     if (iters_out) memcpy(iters_out, ctx->hs.iters, (size_t)n_pairs * sizeof(int));
     if (err_out) memcpy(err_out, ctx->hs.err, (size_t)n_pairs * sizeof(double));
+    return DVO_OK;
+}
+
+int dvo_student_t_fallbacks(const dvo_ctx* ctx, int64_t* count)
+{
+    if (!ctx || !count) return DVO_ERR_INVALID_ARG;
+    *count = ctx->st_fallbacks;
     return DVO_OK;
 }
 

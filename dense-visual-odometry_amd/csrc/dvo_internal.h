@@ -55,6 +55,8 @@ struct DvoReduceParams {
     const double* wparam;       // [n_pairs] lambda (student-t) or k (huber); may be null for WEIGHT_NONE
     const int* active;          // [n_pairs] device-mode: 0 => pair skipped at this level; null => all active
     double* partials;           // [n_pairs][blocks_per_pair][DVO_STRIDE]
+    double* partials2;          // weight mode 4 (Student-t moment form): the r^2-weighted sums, same shape; else unused
+    float lambda0;              // weight mode 5 (Student-t, predicted lambda): 1 / initial_sigma^2 of the first scale pass
     int blocks_per_pair;
     int xcd_remap;              // 1: XCD-aware logical block order
     int finest;                 // level == 0 (kernel-name tag only)
@@ -98,10 +100,17 @@ struct DvoPairState {
     int active;         // 1 while this level is still iterating for this pair
     int iters;          // total GN iterations evaluated
     int pad;
+    double lam_hist[3]; // Student-t one-pass forms: the converged lambda of the last three iterations of this level ([0] newest)
+    int lam_n;          // ... how many of them are valid (reset at every level)
+    int pad2;
 };
 
 struct DvoSolveParams {
     const double* partials;     // [n_pairs][blocks_per_pair][DVO_STRIDE]
+    const double* partials2;    // Student-t moment form: r^2-weighted sums of the same launch, or null
+    int* inexact;               // Student-t one-pass forms: counter of (pair, iteration)s whose bound was not met, or null
+    int predicted;              // 1: the reduction before this control launch was weighted with the predicted lambda (mode 5)
+    double lambda0;             // Student-t: 1 / initial_sigma^2
     int blocks_per_pair;
     int n_pairs;
     DvoPairState* state;        // [n_pairs]

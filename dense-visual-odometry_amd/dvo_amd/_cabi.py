@@ -80,6 +80,7 @@ SIGNATURES = {
     "dvo_comm_destroy": (None, [C.c_void_p]),
     "dvo_comm_last_error": (C.c_char_p, []),
     "dvo_trace_enable": (C.c_int, [_ctx, C.c_int]),
+    "dvo_student_t_fallbacks": (C.c_int, [_ctx, _c_i64_p]),
     "dvo_trace_read": (C.c_int, [_ctx, C.c_int, C.c_void_p]),
     "dvo_profile_enable": (C.c_int, [_ctx, C.c_int]),
     "dvo_profile_read": (C.c_int, [_ctx, _c_i64_p, _c_double_p, C.c_int]),
@@ -431,6 +432,12 @@ class HipContext:
         self._check(self._lib.dvo_profile_read(self._h, launches.ctypes.data_as(_c_i64_p),
                                                ms.ctypes.data_as(_c_double_p), int(bool(reset))))
         return launches, ms
+
+    def student_t_fallbacks(self) -> int:
+        """Solves with the reference's Student-t that had to be repeated with the three-pass form (include/dvo_hip.h)."""
+        n = C.c_int64()
+        self._check(self._lib.dvo_student_t_fallbacks(self._h, C.byref(n)))
+        return int(n.value)
 
     def timer_start(self):
         self._check(self._lib.dvo_timer_start(self._h))

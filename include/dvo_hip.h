@@ -189,9 +189,15 @@ int dvo_residuals_jacobian(dvo_ctx* ctx, int level, int prev_slot, int cur_slot,
  * 160 x 120 pixels run in one persistent launch (a workgroup per pair does all their iterations); finer levels take one
  * reduction launch and one control launch per iteration.
  * Student-t IRLS (weighter/t_weighter.py:21-34): on the persistent levels the reference's loop as written (until
- * |d lambda| < 1e-3, at most 50 passes); on the finer levels DVO_WEIGHT_STUDENT_T runs the TWO scale passes that loop takes
- * whenever the summed scale exceeds 1000 (any image with more than a few hundred non-zero residuals: lambda is then below
- * 1e-3 after the first pass, so the second difference is too) and DVO_WEIGHT_STUDENT_T_MEAN its at most four.
+ * |d lambda| < 1e-3, at most 50 passes).  On the finer levels DVO_WEIGHT_STUDENT_T_MEAN runs its at most four passes, and
+ * DVO_WEIGHT_STUDENT_T the TWO scale passes the reference's loop takes whenever the summed scale exceeds 1000 (any image with
+ * more than a few hundred non-zero residuals: lambda is then below 1e-3 after the first pass, so the second difference is
+ * too) — at levels of 320 x 240 and more evaluated in ONE pass over the points: the scale sum of the second pass and the
+ * weighted normal equations are series in lambda r^2 / 5 (below ~1e-4 there, because the reference's scale is a SUM over
+ * the image) whose terms are moments of the same pass, kept to the order that leaves J^T W J, J^T W r exact to ~1e-9; every
+ * iteration checks a bound on what the series drops, and a batch in which the bound fails (or the loop would not take
+ * exactly two passes) is solved again with the passes as written before dvo_solve_batch / dvo_solve_batch_fetch return.
+ * The environment variable DVO_ST_EXACT (read at dvo_create) forces the passes as written everywhere.
  *   T_init  n_pairs x 12 or NULL (identity)          T_out   n_pairs x 12
  *   xi_out  n_pairs x 6 float64 log of the estimate (may be NULL)
  *   iters_out n_pairs (total GN iterations run, may be NULL)   err_out n_pairs (last accepted error, may be NULL) */
@@ -204,6 +210,8 @@ int dvo_solve_batch_enqueue(dvo_ctx* ctx, int n_pairs, const int* prev_slot, con
                             int max_iterations, double tolerance, int max_increased_steps_allowed, int variant,
                             int weight_mode, double weight_param, const float* T_init);
 int dvo_solve_batch_fetch(dvo_ctx* ctx, int n_pairs, float* T_out, double* xi_out, int* iters_out, double* err_out);
+/* Diagnostic: number of DVO_WEIGHT_STUDENT_T solves this ctx had to repeat with the three-pass form (see above). */
+int dvo_student_t_fallbacks(const dvo_ctx* ctx, int64_t* count);
 
 /* Motion prior of the reference (sigma, base_robust_dvo.py:69-71,:154,:190-194,:217-218) for subsequent
  * dvo_solve_batch calls: H += I/sigma, b += (I/sigma) log(old), err += 0.5 sigma |log(old)|, old <- inc^-1 old, with

@@ -97,16 +97,17 @@ def test_huber_and_student_t_device_vs_oracle(vga_stream):
 
 
 def test_student_t_fast_path_is_bit_identical_to_the_plain_one(vga_stream, monkeypatch):
-    """Student-t device solve: (default) the second scale pass sums the residuals the first pass kept and every kernel
+    """Student-t device solve with the reference's passes as written (DVO_ST_EXACT; the default one-pass moment form has its own
+    test below): the second scale pass sums the residuals the first pass kept and every kernel
     derives its lambda from the per-workgroup sums of the passes before it; DVO_ST_SOLVE_PHASES keeps the cache but
     runs the control kernel after each pass; DVO_NO_RCACHE also recomputes the residuals (the original flow).  Same
     record->lane map and summation orders => identical poses."""
     from dvo_amd.batch import BatchAligner
     st = vga_stream
     out = []
-    for env in ((), ("DVO_ST_SOLVE_PHASES",), ("DVO_NO_RCACHE",)):
-        monkeypatch.delenv("DVO_ST_SOLVE_PHASES", raising=False)
-        monkeypatch.delenv("DVO_NO_RCACHE", raising=False)
+    for env in (("DVO_ST_EXACT",), ("DVO_ST_SOLVE_PHASES",), ("DVO_NO_RCACHE", "DVO_ST_EXACT")):
+        for k in ("DVO_ST_SOLVE_PHASES", "DVO_NO_RCACHE", "DVO_ST_EXACT"):
+            monkeypatch.delenv(k, raising=False)
         for k in env:
             monkeypatch.setenv(k, "1")
         al = BatchAligner(st["K"], st["depth_scale"], 640, 480, 4, max_pairs=8, max_iterations=6,
@@ -115,6 +116,56 @@ def test_student_t_fast_path_is_bit_identical_to_the_plain_one(vga_stream, monke
         al.close()
     for o in out[1:]:
         assert np.array_equal(out[0]["xi"], o["xi"]) and np.array_equal(out[0]["err"], o["err"])
+
+
+def test_student_t_moment_form_equals_the_three_pass_form(frames, vga_stream, monkeypatch):
+    """The reference's Student-t at the per-iteration levels in ONE pass (scale sum of the second IRLS pass and the weighted normal
+    equations from moments of the same pass, include/dvo_hip.h) against the reference's passes as written (DVO_ST_EXACT): the same
+    iteration counts and poses to 2e-8 on the reference's fixture pairs and on rendered pairs, and no solve had to be repeated."""
+    from dvo_amd.batch import BatchAligner
+    for gray, depth, K, scale in ((frames["gray"], frames["depth"], frames["K"], frames["depth_scale"]),
+                                  (vga_stream["gray"], vga_stream["depth"], vga_stream["K"], vga_stream["depth_scale"])):
+        out = []
+        for exact in (False, True):
+            monkeypatch.delenv("DVO_ST_EXACT", raising=False)
+            if exact:
+                monkeypatch.setenv("DVO_ST_EXACT", "1")
+            al = BatchAligner(K, scale, 640, 480, 4, max_pairs=16, max_iterations=10, weighting="student_t_reference")
+            out.append(al.align_host(gray[:10], depth[:10]))
+            assert al.ctx.student_t_fallbacks() == 0
+            al.close()
+        monkeypatch.delenv("DVO_ST_EXACT", raising=False)
+        assert np.array_equal(out[0]["iters"], out[1]["iters"])
+        assert np.max(np.abs(out[0]["xi"] - out[1]["xi"])) < 2e-8
+        np.testing.assert_allclose(out[0]["err"], out[1]["err"], rtol=1e-6)
+
+
+def test_student_t_moment_form_falls_back_when_its_bound_fails():
+    """Two identical frames except a handful of saturated pixels: the summed scale is small, lambda is not, and the series the
+    one-pass form relies on does not apply.  Every iteration flags it, the solve is repeated with the passes as written, and the
+    result is bit-identical to a context that never used the one-pass form."""
+    import os
+    from dvo_amd import synthetic
+    from dvo_amd.batch import BatchAligner
+    st = synthetic.make_stream(2, 640, 480, seed=5)
+    gray = np.stack([st["gray"][0], st["gray"][0]]).copy()
+    rng = np.random.default_rng(3)
+    ys, xs = rng.integers(40, 440, 40), rng.integers(40, 600, 40)
+    gray[1, ys, xs] = 255 - gray[1, ys, xs]
+    depth = np.stack([st["depth"][0], st["depth"][0]])
+    res = []
+    for exact in (False, True):
+        os.environ.pop("DVO_ST_EXACT", None)
+        if exact:
+            os.environ["DVO_ST_EXACT"] = "1"
+        try:
+            al = BatchAligner(st["K"], st["depth_scale"], 640, 480, 2, max_pairs=1, max_iterations=4, weighting="student_t_reference")
+            res.append(al.align_host(gray, depth))
+            assert al.ctx.student_t_fallbacks() == (0 if exact else 1)
+            al.close()
+        finally:
+            os.environ.pop("DVO_ST_EXACT", None)
+    assert np.array_equal(res[0]["xi"], res[1]["xi"]) and np.array_equal(res[0]["iters"], res[1]["iters"])
 
 
 def test_config3_1280x960_five_levels_huber():
