@@ -96,6 +96,7 @@ struct dvo_ctx {
     SolveKey last_key;
     bool last_has_init = false;
     int64_t st_fallbacks = 0;            // solves repeated with the three-pass form
+    unsigned long long* d_small_stamps = nullptr;   // DVO_SMALL_STAMPS: [max_pairs][8] phase clocks of k_gn_small (diagnostic)
     float* d_rcache = nullptr;           // Student-t device solve: residuals kept between the scale passes [max_pairs][max_w*max_h]
     uint32_t* d_exp_gradh = nullptr;     // DVO_EXP_TAPS side planes [n_slots][exp_plane_texels]: {f16 gx, f16 gy} / intensity
     uint8_t* d_exp_ipl = nullptr;
@@ -506,6 +507,10 @@ int dvo_create(int device, int max_w, int max_h, int max_levels, int n_slots, in
         ctx->knobs.no_rcache = getenv("DVO_NO_RCACHE") != nullptr;
         ctx->knobs.ingest_unfused = getenv("DVO_INGEST_UNFUSED") != nullptr;
         ctx->knobs.st_exact = getenv("DVO_ST_EXACT") != nullptr;
+        if (getenv("DVO_SMALL_STAMPS") != nullptr) {
+            CREATE_TRY(hipMalloc((void**)&ctx->d_small_stamps, (size_t)max_pairs * 8 * sizeof(unsigned long long)));
+            CREATE_TRY(hipMemset(ctx->d_small_stamps, 0, (size_t)max_pairs * 8 * sizeof(unsigned long long)));
+        }
         e = getenv("DVO_EXP_TAPS");
         if (e) ctx->knobs.exp_taps = atoi(e);
         e = getenv("DVO_SMALL_MAX_PIX");
@@ -538,7 +543,7 @@ void dvo_destroy(dvo_ctx* ctx)
     void* dev[] = {ctx->d_slots, ctx->d_prev, ctx->d_cur, ctx->d_T, ctx->d_Tinit, ctx->d_wparam, ctx->d_active, ctx->d_partials,
                    ctx->d_out, ctx->d_state, ctx->d_xi, ctx->d_iters, ctx->d_err, ctx->d_stage_img, ctx->d_dense, ctx->d_trace, ctx->d_frame_slots, ctx->d_prior, ctx->d_batch_stage,
                    ctx->d_list_count, ctx->d_seg_counts, ctx->d_rcache, ctx->d_scale1, ctx->d_scale2, ctx->d_irls_done,
-                   ctx->d_exp_gradh, ctx->d_exp_ipl, ctx->d_partials2, ctx->d_inexact};
+                   ctx->d_exp_gradh, ctx->d_exp_ipl, ctx->d_partials2, ctx->d_inexact, ctx->d_small_stamps};
     for (void* p : dev) if (p) (void)hipFree(p);
     void* host[] = {ctx->hs.prev, ctx->hs.cur, ctx->hs.T, ctx->hs.wparam, ctx->hs.out, ctx->hs.xi, ctx->hs.iters, ctx->hs.err, ctx->h_frame_slots, ctx->h_prior,
                     ctx->h_inexact};
@@ -1115,7 +1120,10 @@ static int record_solve(dvo_ctx* ctx, const SolveKey& k, const float* d_init)
         int n = 0;
         // a handful of pairs cannot fill the chip either way: there a 160x120 level (13 k records) is faster spread over its ~19
         // workgroups than inside one, so only levels up to 80x60 go to the persistent kernel (single pair: 0.87 -> 0.77 ms)
-        const int max_pix = (n_pairs <= 16) ? (ctx->knobs.small_max_pix < 4800 ? ctx->knobs.small_max_pix : 4800) : ctx->knobs.small_max_pix;
+        // (not with a Student-t weighting: the persistent kernel runs the reference's IRLS loop as written, the per-iteration
+        // launches a fixed number of passes, and a pair must not get a different lambda because of the size of its batch)
+        const bool student_t = (weight_mode == DVO_WEIGHT_STUDENT_T || weight_mode == DVO_WEIGHT_STUDENT_T_MEAN);
+        const int max_pix = (n_pairs <= 16 && !student_t) ? (ctx->knobs.small_max_pix < 4800 ? ctx->knobs.small_max_pix : 4800) : ctx->knobs.small_max_pix;
         while (level - n >= 0 && n < DVO_SMALL_LEVELS && g[level - n].npix <= max_pix) {
             sp.level_id[n] = level - n;
             sp.level_iters[n] = k.level_iters[level - n];
@@ -1148,6 +1156,7 @@ static int record_solve(dvo_ctx* ctx, const SolveKey& k, const float* d_init)
             sp.trace = ctx->d_trace;
             sp.trace_stride = DVO_STRIDE + 18;
             sp.trace_cap = ctx->trace_cap;
+            sp.stamps = ctx->d_small_stamps;
             // workgroup size: the whole batch should be resident at once (<= 2048 threads per CU at <= 128 VGPRs); a single
             // pair gets the widest workgroup (latency), a large batch narrower ones (more pairs in flight per CU)
             int threads = ctx->knobs.small_threads;
@@ -1382,6 +1391,17 @@ int dvo_solve_batch_fetch(dvo_ctx* ctx, int n_pairs, float* T_out, double* xi_ou
     if (xi_out) memcpy(xi_out, ctx->hs.xi, (size_t)n_pairs * 6 * sizeof(double));
     if (iters_out) memcpy(iters_out, ctx->hs.iters, (size_t)n_pairs * sizeof(int));
     if (err_out) memcpy(err_out, ctx->hs.err, (size_t)n_pairs * sizeof(double));
+    return DVO_OK;
+}
+
+int dvo_debug_small_stamps(dvo_ctx* ctx, int n_pairs, uint64_t* out, int reset)
+{
+    if (!ctx || !out || n_pairs <= 0 || n_pairs > ctx->max_pairs) return DVO_ERR_INVALID_ARG;
+    if (!ctx->d_small_stamps) return fail(ctx, DVO_ERR_BAD_STATE, "dvo_debug_small_stamps: create the ctx with DVO_SMALL_STAMPS set");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, hipMemcpy(out, ctx->d_small_stamps, (size_t)n_pairs * 8 * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    if (reset) HIP_TRY(ctx, hipMemset(ctx->d_small_stamps, 0, (size_t)ctx->max_pairs * 8 * sizeof(unsigned long long)));
     return DVO_OK;
 }
 

@@ -161,6 +161,9 @@ struct DvoSmallParams {
     int* irls_done;              // unused here (the IRLS loop runs inside the kernel); null
     double* trace;
     int trace_stride, trace_cap;
+    unsigned long long* stamps;  // diagnostic (DVO_SMALL_STAMPS): [n_pairs][8] shader-clock ticks thread 0 of the workgroup spent in
+                                 // {record loops, wave reduction + barrier, cross-wave sum + barrier, control step + barrier,
+                                 //  Student-t scale passes, whole kernel}; or null
 };
 
 struct DvoBatchIngestParams {

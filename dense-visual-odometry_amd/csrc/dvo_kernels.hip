@@ -1501,11 +1501,51 @@ __device__ __forceinline__ double rcp64(double x)
     return fma(e, r, r);
 }
 
+// sqrt(x) for a float64 x >= 0 in the normal range (or 0): v_rsq_f64 + two Newton steps on the reciprocal root, then x * rsqrt(x)
+// with one correction: <= 1 ulp, ~12 instructions instead of the ~30 of the IEEE sqrt expansion (control step = instruction count).
+__device__ __forceinline__ double sqrt64_fast(double x)
+{
+    if (!(x > 1e-300)) return (x == 0.0) ? 0.0 : sqrt(x);
+    double y = __builtin_amdgcn_rsq(x);
+    const double hx = 0.5 * x;
+    y = y * fma(-hx * y, y, 1.5);
+    y = y * fma(-hx * y, y, 1.5);
+    const double s = x * y;
+    return fma(fma(-s, s, x), 0.5 * y, s);
+}
+
+// sin(a), cos(a) of the half rotation angle a = theta / 2.  Between consecutive frames |a| is ~1e-3: the Taylor series to a^15 /
+// a^14 is exact to float64 rounding for |a| <= 0.25 (next term a^17 / 17! < 2e-25) in 2 x 7 FMAs; larger angles take the library
+// routine (with its range reduction: ~150 instructions).
+__device__ __forceinline__ void sincos_half_angle(double a, double* s, double* c)
+{
+    if (fabs(a) <= 0.25) {
+        const double z = a * a;
+        double ps = fma(z, -1.0 / 1307674368000.0, 1.0 / 6227020800.0);
+        ps = fma(z, ps, -1.0 / 39916800.0);
+        ps = fma(z, ps, 1.0 / 362880.0);
+        ps = fma(z, ps, -1.0 / 5040.0);
+        ps = fma(z, ps, 1.0 / 120.0);
+        ps = fma(z, ps, -1.0 / 6.0);
+        *s = fma(a * z, ps, a);
+        double pc = fma(z, -1.0 / 87178291200.0, 1.0 / 479001600.0);
+        pc = fma(z, pc, -1.0 / 3628800.0);
+        pc = fma(z, pc, 1.0 / 40320.0);
+        pc = fma(z, pc, -1.0 / 720.0);
+        pc = fma(z, pc, 1.0 / 24.0);
+        pc = fma(z, pc, -0.5);
+        *c = fma(z, pc, 1.0);
+        return;
+    }
+    sincos(a, s, c);
+}
+
 // Se3.from_se3 (special_euclidean_group.py:105-123): xi = (upsilon, omega) -> (q, t = V upsilon)
 __device__ inline void se3_from_xi(const double* xi, double* q, double* t)
 {
     const double ox = xi[3], oy = xi[4], oz = xi[5];
-    double theta = sqrt(ox * ox + oy * oy + oz * oz);
+    const double th2 = ox * ox + oy * oy + oz * oz;
+    double theta = sqrt64_fast(th2);
     if (theta < DVO_LIE_EPS) {
         q[0] = 1; q[1] = q[2] = q[3] = 0;
         t[0] = xi[0]; t[1] = xi[1]; t[2] = xi[2];
@@ -1526,7 +1566,7 @@ __device__ inline void se3_from_xi(const double* xi, double* q, double* t)
         }
     }
     double s2, c2;
-    sincos(th * 0.5, &s2, &c2);
+    sincos_half_angle(th * 0.5, &s2, &c2);
     const double rth = rcp64(th);
     const double k = s2 * rth;
     q[0] = c2; q[1] = k * px; q[2] = k * py; q[3] = k * pz;
@@ -1677,15 +1717,17 @@ __device__ __forceinline__ void solve6(const double* hu, const double* b, double
     double a[21];
 #pragma unroll
     for (int q = 0; q < 21; ++q) a[q] = hu[q];
-    bool finite = true;
-    double dmax = 0.0;
+    // every entry finite <=> the sum of their magnitudes is (27 adds and one class test instead of 27 class tests; a sum that
+    // overflows to infinity although every term is finite would need entries beyond 1e306)
+    double dmax = 0.0, mag = 0.0;
 #pragma unroll
     for (int i = 0; i < 6; ++i) {
         dmax = fmax(dmax, fabs(a[lo6(i, i)]));
-        finite = finite && isfinite(b[i]);
+        mag += fabs(b[i]);
     }
 #pragma unroll
-    for (int q = 0; q < 21; ++q) finite = finite && isfinite(a[q]);
+    for (int q = 0; q < 21; ++q) mag += fabs(a[q]);
+    const bool finite = isfinite(mag);
     if (!finite) {
 #pragma unroll
         for (int i = 0; i < 6; ++i) x[i] = __builtin_nan("");
@@ -2119,28 +2161,48 @@ __device__ __forceinline__ void wave_reduce_terms(const float* acc, float* wbuf 
     if (lane >= DVO_NACC && lane < DVO_STRIDE) out[lane] = 0.0;
 }
 
-template <int VARIANT, int WMODE, bool SKEW>
-__global__ __launch_bounds__(DVO_SMALL_MAX_THREADS) void k_gn_small(const DvoSmallParams p)
+// THREADS = the launched workgroup size (256 / 512 / 1024): the launch bound then equals it, so the narrow workgroups of the
+// large-batch case are not held to the 128 registers a 1024-thread workgroup allows (the one-lane float64 control step needs
+// ~160 live registers at its peak; under the 128 cap it spilled 82-112 of them into scratch on every iteration).
+template <int VARIANT, int WMODE, bool SKEW, int THREADS>
+#ifndef DVO_SMALL_MINW
+#define DVO_SMALL_MINW 3
+#endif
+__global__ __launch_bounds__(THREADS, (THREADS == DVO_SMALL_MAX_THREADS) ? 4 : DVO_SMALL_MINW) void k_gn_small(const DvoSmallParams p)
 {
     static_assert(VARIANT == 0 || VARIANT == 1 || VARIANT == 3, "V3 keeps the per-iteration launches");
+    static_assert(THREADS == 256 || THREADS == 512 || THREADS == DVO_SMALL_MAX_THREADS, "workgroup sizes of dvo_launch_gn_small");
+    constexpr int NWAVES = THREADS / 64;
     __shared__ DvoPairState st;
     __shared__ float T_sh[12];
     __shared__ int active_sh;
     __shared__ double wpar_sh;
     __shared__ double rec_sh[DVO_STRIDE];
-    __shared__ double wsum[DVO_SMALL_MAX_WAVES][DVO_STRIDE];
-    __shared__ double scal[2][DVO_SMALL_MAX_WAVES];
-    __shared__ double scnt_sh[2][DVO_SMALL_MAX_WAVES];
-    __shared__ float wbuf[DVO_SMALL_MAX_WAVES][8 * 65];
+    __shared__ double wsum[(NWAVES * DVO_STRIDE >= 72) ? NWAVES : 3][DVO_STRIDE];      // (also the 72-double workspace of solve6_pinv)
+    __shared__ double scal[2][NWAVES];
+    __shared__ double scnt_sh[2][NWAVES];
+    __shared__ float wbuf[NWAVES][8 * 65];
     const int pair = blockIdx.x, tid = threadIdx.x;
-    const int lane_ = tid & 63, wave_ = tid >> 6, nwaves = (int)blockDim.x >> 6;
+    const int lane_ = tid & 63, wave_ = tid >> 6;
+    constexpr int nwaves = NWAVES;
     if (tid == 0) { st = p.state[pair]; active_sh = 1; wpar_sh = p.wparam[pair]; }
     if (tid < 12) T_sh[tid] = p.T[(size_t)pair * 12 + tid];
     const int prev_id = p.prev_slot[pair];
     const uint8_t* prev = p.slots + (size_t)prev_id * p.slot_stride;
     const uint8_t* curs = p.slots + (size_t)p.cur_slot[pair] * p.slot_stride;
-    const int gstride = (int)blockDim.x * DVO_PX_PER_THREAD;                      // records per group of the workgroup
+    constexpr int gstride = THREADS * DVO_PX_PER_THREAD;                          // records per group of the workgroup
     const int rec0 = wave_ * (64 * DVO_PX_PER_THREAD);
+    // diagnostic stamps (p.stamps != null only under DVO_SMALL_STAMPS; workgroup-uniform branches around s_memtime otherwise)
+    const bool stamping = p.stamps != nullptr;
+    unsigned long long tk[6] = {0, 0, 0, 0, 0, 0}, t_last = 0, t_begin = 0;
+    auto stamp = [&](int k) {
+        if (stamping) {
+            const unsigned long long now = __builtin_amdgcn_s_memtime();
+            tk[k] += now - t_last;
+            t_last = now;
+        }
+    };
+    if (stamping) { t_begin = __builtin_amdgcn_s_memtime(); t_last = t_begin; }
 
     for (int li = 0; li < p.n_levels; ++li) {
         const DvoLevelGeom& g = p.g[li];
@@ -2238,6 +2300,7 @@ __global__ __launch_bounds__(DVO_SMALL_MAX_THREADS) void k_gn_small(const DvoSma
                 }
                 wpar = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint((float)cur)));
                 if (mean && tid == 0) wpar_sh = cur;          // (every thread read wpar_sh before the first barrier of the loop)
+                stamp(4);
             }
 
             float acc[DVO_NACC];
@@ -2286,34 +2349,48 @@ __global__ __launch_bounds__(DVO_SMALL_MAX_THREADS) void k_gn_small(const DvoSma
                 }
             }
             if constexpr (WMODE == 0) acc[DVO_NACC - 1] = acc[DVO_NACC - 3];
+            stamp(0);
             wave_reduce_terms(acc, wbuf[wave_], wsum[wave_]);
             __syncthreads();
+            stamp(1);
             if (tid < DVO_STRIDE) {
                 double t = 0.0;
                 for (int w = 0; w < nwaves; ++w) t += wsum[w][tid];                  // fixed order
                 rec_sh[tid] = t;
             }
             __syncthreads();
+            stamp(2);
             if (tid == 0) gn_control(p, 0, pair, st, T_sh, &active_sh, &wpar_sh, rec_sh, &wsum[0][0]);
             __syncthreads();
+            stamp(3);
         }
         __syncthreads();
     }
     if (tid == 0) { p.state[pair] = st; p.active[pair] = active_sh; p.wparam[pair] = wpar_sh; }
     if (tid < 12) p.T[(size_t)pair * 12 + tid] = T_sh[tid];
+    if (stamping && tid == 0) {
+        tk[5] = __builtin_amdgcn_s_memtime() - t_begin;
+        for (int k = 0; k < 6; ++k) p.stamps[(size_t)pair * 8 + k] += tk[k];
+    }
 }
 
 hipError_t dvo_launch_gn_small(const DvoSmallParams& p, int variant, int threads, hipStream_t s)
 {
     const dim3 grid((unsigned)p.n_pairs), block((unsigned)threads);
     const bool skew = !p.cam[0].skew0;
-#define DVO_SMALL_LAUNCH(V, W, S) hipLaunchKernelGGL((k_gn_small<V, W, S>), grid, block, 0, s, p)
+#define DVO_SMALL_LAUNCH(V, W, S)                                                                            \
+    do {                                                                                                     \
+        if (threads == 256) hipLaunchKernelGGL((k_gn_small<V, W, S, 256>), grid, block, 0, s, p);          \
+        else if (threads == 512) hipLaunchKernelGGL((k_gn_small<V, W, S, 512>), grid, block, 0, s, p);     \
+        else hipLaunchKernelGGL((k_gn_small<V, W, S, DVO_SMALL_MAX_THREADS>), grid, block, 0, s, p);        \
+    } while (0)
 #define DVO_SMALL_W(V, S)                                                     \
     do {                                                                      \
         if (p.weight_mode == 0) DVO_SMALL_LAUNCH(V, 0, S);                    \
         else if (p.weight_mode == 1 || p.weight_mode == 3) DVO_SMALL_LAUNCH(V, 1, S);   \
         else DVO_SMALL_LAUNCH(V, 2, S);                                       \
     } while (0)
+    if (threads != 256 && threads != 512 && threads != DVO_SMALL_MAX_THREADS) return hipErrorInvalidValue;
     if (variant == 0) { if (skew) DVO_SMALL_W(0, true); else DVO_SMALL_W(0, false); }
     else if (variant == 1) { if (skew) DVO_SMALL_W(1, true); else DVO_SMALL_W(1, false); }
     else if (variant == 3) { if (skew) DVO_SMALL_W(3, true); else DVO_SMALL_W(3, false); }

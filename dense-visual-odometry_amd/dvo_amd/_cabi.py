@@ -81,6 +81,7 @@ SIGNATURES = {
     "dvo_comm_last_error": (C.c_char_p, []),
     "dvo_trace_enable": (C.c_int, [_ctx, C.c_int]),
     "dvo_student_t_fallbacks": (C.c_int, [_ctx, _c_i64_p]),
+    "dvo_debug_small_stamps": (C.c_int, [_ctx, C.c_int, C.c_void_p, C.c_int]),
     "dvo_trace_read": (C.c_int, [_ctx, C.c_int, C.c_void_p]),
     "dvo_profile_enable": (C.c_int, [_ctx, C.c_int]),
     "dvo_profile_read": (C.c_int, [_ctx, _c_i64_p, _c_double_p, C.c_int]),
@@ -438,6 +439,12 @@ class HipContext:
         n = C.c_int64()
         self._check(self._lib.dvo_student_t_fallbacks(self._h, C.byref(n)))
         return int(n.value)
+
+    def small_stamps(self, n_pairs: int, reset: bool = True) -> np.ndarray:
+        """(n_pairs, 8) uint64 phase clocks of the persistent small-level kernel (ctx created under DVO_SMALL_STAMPS)."""
+        out = np.zeros((n_pairs, 8), dtype=np.uint64)
+        self._check(self._lib.dvo_debug_small_stamps(self._h, n_pairs, _ptr(out), int(bool(reset))))
+        return out
 
     def timer_start(self):
         self._check(self._lib.dvo_timer_start(self._h))

@@ -140,6 +140,22 @@ def test_student_t_moment_form_equals_the_three_pass_form(frames, vga_stream, mo
         np.testing.assert_allclose(out[0]["err"], out[1]["err"], rtol=1e-6)
 
 
+def test_student_t_result_does_not_depend_on_the_batch_size(frames):
+    """The same frame pair solved in a batch of 16 and in a batch of 17 (the size at which the unweighted solve moves the 160x120
+    level into the persistent kernel): with the reference's Student-t every level up to 160x120 runs the reference's IRLS loop in
+    the persistent kernel whatever the batch size, so the poses agree to float32 summation noise."""
+    from dvo_amd.batch import BatchAligner
+    res = []
+    for n in (16, 17):
+        gray = np.stack([frames["gray"][k % 2] for k in range(n + 1)])
+        depth = np.stack([frames["depth"][k % 2] for k in range(n + 1)])
+        al = BatchAligner(frames["K"], frames["depth_scale"], 640, 480, 4, max_pairs=n, max_iterations=10, weighting="student_t_reference")
+        res.append(al.align_host(gray, depth))
+        al.close()
+    assert np.array_equal(res[0]["iters"][:2], res[1]["iters"][:2])
+    assert np.max(np.abs(res[0]["xi"][:2] - res[1]["xi"][:2])) < 1e-7
+
+
 def test_student_t_moment_form_falls_back_when_its_bound_fails():
     """Two identical frames except a handful of saturated pixels: the summed scale is small, lambda is not, and the series the
     one-pass form relies on does not apply.  Every iteration flags it, the solve is repeated with the passes as written, and the
