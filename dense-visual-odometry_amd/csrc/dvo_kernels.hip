@@ -1976,7 +1976,12 @@ __device__ __forceinline__ void gn_control(const P& p, int phase, int pair, DvoP
         for (int i = 0; i < 6; ++i) { rec[dg[i]] += p.inv_sigma; bneg[i] += p.inv_sigma * xo[i]; nrm += xo[i] * xo[i]; }
         err += 0.5 * (1.0 / p.inv_sigma) * sqrt(nrm);
     }
+    // (compiler fences around the solve: without them the loads of the pose state, of the trace pointers and of the record are
+    // all hoisted to the top of the control step and stay live across it — the step is one lane's serial program and its
+    // register peak, not its latency, is what matters inside k_gn_small)
+    asm volatile("" ::: "memory");
     solve6(rec, bneg, inc, ws);
+    asm volatile("" ::: "memory");
     if (one_pass && inexact != nullptr) {
         // what the one-pass form neglects moves the increment by at most ~dbound_k / H_kk per component (Cauchy-Schwarz bounds,
         // 1.2-14 x the true difference on the reference's fixtures): keep that inside the 1e-5 parity bound, else count the
@@ -2001,6 +2006,7 @@ __device__ __forceinline__ void gn_control(const P& p, int phase, int pair, DvoP
         for (int i = 0; i < 6; ++i) tr[DVO_STRIDE + i] = inc[i];
         for (int i = 0; i < 12; ++i) tr[DVO_STRIDE + 6 + i] = (double)T[i];
     }
+    asm volatile("" ::: "memory");
     const double diff = err - st.err_prev;
     bool stop = false;
     if (fabs(diff) < p.tolerance) {                                                     // :207
@@ -2165,10 +2171,7 @@ __device__ __forceinline__ void wave_reduce_terms(const float* acc, float* wbuf 
 // large-batch case are not held to the 128 registers a 1024-thread workgroup allows (the one-lane float64 control step needs
 // ~160 live registers at its peak; under the 128 cap it spilled 82-112 of them into scratch on every iteration).
 template <int VARIANT, int WMODE, bool SKEW, int THREADS>
-#ifndef DVO_SMALL_MINW
-#define DVO_SMALL_MINW 3
-#endif
-__global__ __launch_bounds__(THREADS, (THREADS == DVO_SMALL_MAX_THREADS) ? 4 : DVO_SMALL_MINW) void k_gn_small(const DvoSmallParams p)
+__device__ __forceinline__ void gn_small_body(const DvoSmallParams& p)
 {
     static_assert(VARIANT == 0 || VARIANT == 1 || VARIANT == 3, "V3 keeps the per-iteration launches");
     static_assert(THREADS == 256 || THREADS == 512 || THREADS == DVO_SMALL_MAX_THREADS, "workgroup sizes of dvo_launch_gn_small");
@@ -2374,15 +2377,38 @@ __global__ __launch_bounds__(THREADS, (THREADS == DVO_SMALL_MAX_THREADS) ? 4 : D
     }
 }
 
+// The three launched shapes.  The register budget is part of the shape: a 1024-thread workgroup is 4 waves per SIMD = 128 VGPRs;
+// the narrow workgroups are compiled for 3 waves per SIMD (168 VGPRs): beside one such wave a SIMD still holds three
+// 96-register waves of another stream's reduction.  (The budget comes in steps of 512 / waves: the next one, 256, lets the
+// control step run without spills and the isolated launch finish 11 % sooner, but costs the four-stream job 1 %.)
+#ifndef DVO_SMALL_MINW
+#define DVO_SMALL_MINW 3
+#endif
+template <int VARIANT, int WMODE, bool SKEW>
+__global__ __launch_bounds__(256, DVO_SMALL_MINW) void k_gn_small_256(const DvoSmallParams p)
+{
+    gn_small_body<VARIANT, WMODE, SKEW, 256>(p);
+}
+template <int VARIANT, int WMODE, bool SKEW>
+__global__ __launch_bounds__(512, DVO_SMALL_MINW) void k_gn_small_512(const DvoSmallParams p)
+{
+    gn_small_body<VARIANT, WMODE, SKEW, 512>(p);
+}
+template <int VARIANT, int WMODE, bool SKEW>
+__global__ __launch_bounds__(DVO_SMALL_MAX_THREADS) void k_gn_small_1024(const DvoSmallParams p)
+{
+    gn_small_body<VARIANT, WMODE, SKEW, DVO_SMALL_MAX_THREADS>(p);
+}
+
 hipError_t dvo_launch_gn_small(const DvoSmallParams& p, int variant, int threads, hipStream_t s)
 {
     const dim3 grid((unsigned)p.n_pairs), block((unsigned)threads);
     const bool skew = !p.cam[0].skew0;
 #define DVO_SMALL_LAUNCH(V, W, S)                                                                            \
     do {                                                                                                     \
-        if (threads == 256) hipLaunchKernelGGL((k_gn_small<V, W, S, 256>), grid, block, 0, s, p);          \
-        else if (threads == 512) hipLaunchKernelGGL((k_gn_small<V, W, S, 512>), grid, block, 0, s, p);     \
-        else hipLaunchKernelGGL((k_gn_small<V, W, S, DVO_SMALL_MAX_THREADS>), grid, block, 0, s, p);        \
+        if (threads == 256) hipLaunchKernelGGL((k_gn_small_256<V, W, S>), grid, block, 0, s, p);            \
+        else if (threads == 512) hipLaunchKernelGGL((k_gn_small_512<V, W, S>), grid, block, 0, s, p);       \
+        else hipLaunchKernelGGL((k_gn_small_1024<V, W, S>), grid, block, 0, s, p);                          \
     } while (0)
 #define DVO_SMALL_W(V, S)                                                     \
     do {                                                                      \
