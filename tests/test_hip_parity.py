@@ -608,7 +608,7 @@ def test_maximum_image_size_properties():
 
 
 def test_projection_division_is_bit_identical_to_ieee(hip):
-    """The projection's quotient (shared reciprocal + two correction steps, no v_div_scale / v_div_fixup) against the
+    """The projection's quotient (shared refined reciprocal + ONE residual correction, no v_div_scale / v_div_fixup) against the
     compiler's IEEE division on the device and against NumPy, over the operand ranges the projection sees."""
     ctx, _ = hip
     rng = np.random.default_rng(2024)
@@ -619,6 +619,15 @@ def test_projection_division_is_bit_identical_to_ieee(hip):
         out, ref = ctx.debug_divide(a, b)
         assert np.array_equal(out.view(np.uint32), ref.view(np.uint32))
         assert np.array_equal(out, a / b)
+    # divisors whose mantissa is all ones, or all ones but the last bits (the case Markstein's theorem on the one-correction quotient
+    # excepts), against numerators of every kind; tools/ubench/quotient3.hip sweeps every mantissa on the device
+    m = np.concatenate([np.full(1 << 18, 0x7FFFFF, dtype=np.uint32), rng.integers(0x7FFFF0, 0x800000, 1 << 18, dtype=np.uint32)])
+    e = rng.integers(120, 132, m.size, dtype=np.uint32)
+    b = ((e << 23) | m).view(np.float32)
+    a = (rng.uniform(-1.0, 1.0, m.size) * 3000.0 * b).astype(np.float32)
+    a[::7] = (b[::7] * np.float32(1.9999999)).astype(np.float32)
+    out, ref = ctx.debug_divide(a, b)
+    assert np.array_equal(out.view(np.uint32), ref.view(np.uint32)) and np.array_equal(out, a / b)
     # negative / tiny denominators keep the same answer too; zero gives a non-finite value (pixel invalid either way)
     b = np.array([-2.5, -0.01, 1e-20, 0.0], dtype=np.float32)
     a = np.array([100.0, 3.0, 1e-18, 5.0], dtype=np.float32)
