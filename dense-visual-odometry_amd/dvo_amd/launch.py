@@ -3,7 +3,8 @@
 `python bench.py --gpus N` must produce an N-rank measurement by itself (the driver's command shape), so when a
 script is asked for N > 1 GPUs and was not itself started by a launcher (no WORLD_SIZE in the environment) it calls
 `launch_ranks` *before anything has touched the GPU*: N fresh child processes under `torch.distributed.run`
-(rendezvous on 127.0.0.1, a free port), stdout / stderr relayed, exit code returned.  Nothing is ever exec'ed from a
+(`--standalone --local-addr 127.0.0.1`: the rendezvous store picks its own port), stdout / stderr inherited, exit code
+returned; a finite timeout after which the whole process group of the launcher is terminated.  Nothing is ever exec'ed from a
 process that has initialised HIP: the children are new interpreters, and this parent only counts devices
 (`torch.cuda.device_count()` does not initialise the runtime on this image) and waits.
 
@@ -12,7 +13,6 @@ The reference has no distributed code; this is the build's own cont
 from __future__ import annotations
 
 import os
-import socket
 import subprocess
 import sys
 from typing import Optional, Sequence
@@ -20,14 +20,6 @@ from typing import Optional, Sequence
 
 class LaunchError(RuntimeError):
     pass
-
-
-def free_port() -> int:
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    port = s.getsockname()[1]
-    s.close()
-    return port
 
 
 def started_by_launcher(env=None) -> bool:
