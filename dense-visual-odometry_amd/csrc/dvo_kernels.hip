@@ -1082,7 +1082,9 @@ __global__ __launch_bounds__(DVO_BLOCK, (VARIANT == 2) ? 2 : DVO_REDUCE_WAVES_PE
         }
         wpar = (float)lam;
     }
-    const float lam0 = (WMODE == 5) ? p.lambda0 : 0.0f;          // WMODE 5: wpar = the PREDICTED lambda of this iteration
+    // WMODE 4 / 5: the first scale pass runs under the CONSTANT lambda0 (p.lambda0); wparam[pair] (wpar) is the predicted lambda of
+    // this iteration (used by WMODE 5 only: from the second iteration of a level on it no longer holds lambda0)
+    const float lam0 = (WMODE == 4 || WMODE == 5) ? p.lambda0 : 0.0f;
 
     float acc[NACC];
 #pragma unroll
@@ -1199,7 +1201,7 @@ __global__ __launch_bounds__(DVO_BLOCK, (VARIANT == 2) ? 2 : DVO_REDUCE_WAVES_PE
                     }
                     if constexpr (WMODE == 4) {
                         // first scale pass under the constant lambda0 (t_weighter.py:23, :43-45), exact per point
-                        acc[29] += r2 * (6.0f * fast_rcp(fmaf(r2, wpar, 5.0f)));
+                        acc[29] += r2 * (6.0f * fast_rcp(fmaf(r2, lam0, 5.0f)));
                         // r^2-weighted normal equations and the even moments r^4, r^6, r^8
                         float rj[6];
 #pragma unroll
