@@ -17,6 +17,7 @@ The JSON line also carries
   cpu_baseline — the NumPy oracle (a port of the reference CPU path) timed on this host on a bounded sample
 and, at N = 1 on the default workload, outside the `value` region (BASELINE.json north_star's report):
   config3             — configs[2]: 1280x960, 5 levels, Huber: frame-pairs/s and its own level-0 roofline object
+                        (also for N > 1: every rank runs it, rank 0 reports the aggregate and the per-rank figures)
   pcie_inclusive      — the same solve fed from page-locked host memory (gray and colour, 2 / 4 slices)
   student_t_reference — the reference's own robust weighting (use_weighter=True) on the metric's workload
   production_mode     — the build's Gauss-Newton mode (build-defined)
@@ -69,6 +70,8 @@ def parse_args():
     ap.add_argument("--distinct", type=int, default=0, help="distinct rendered frames (0 = batch+1)")
     ap.add_argument("--spawn", action="store_true",
                     help="start the ranks through the launcher even for --gpus 1 (rehearses the multi-GPU entry on one GPU)")
+    ap.add_argument("--config3-all-ranks", action="store_true",
+                    help="run the 1280x960 leg on every rank and gather it (default for N > 1; this flag forces it for the one-rank rehearsal)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true",
                     help="skip the legs beside the metric (production mode, Student-t, PCIe-inclusive, 1280x960 config 3, fixture ATE): A/B scripts")
@@ -257,7 +260,7 @@ def leg_pcie(st, gray, depth, B, W, H, L, iterations, device, steps):
     return out
 
 
-def leg_config3(device, iterations, streams, steps):
+def leg_config3(device, iterations, streams, steps, seed=1234):
     """BASELINE.json configs[2]: synthetic 1280x960 RGB-D stream, 5-level pyramid, Huber weighting, 1 GPU.  The largest batch of
     512 / 256 / 128 pairs that fits; 129 rendered frames played forwards and backwards (every pair is two consecutive renders)."""
     import numpy as np
@@ -266,7 +269,7 @@ def leg_config3(device, iterations, streams, steps):
     from dvo_amd.batch import StreamedAligner
     W, H, L = 1280, 960, 5
     n_render = 129
-    st = synthetic.make_stream(n_render, W, H, seed=1234, device="cuda", as_torch=True)
+    st = synthetic.make_stream(n_render, W, H, seed=seed, device="cuda", as_torch=True)
     last_err = None
     for B in (512, 256, 128):
         al = None
@@ -524,7 +527,30 @@ def main():
             out["production_mode"] = gn_mode
     al.close()
     al = None
+    # config 3 (1280x960 x 5 levels, Huber) on EVERY rank when N > 1: north_star asks for both image sizes at 1 / 2 / 4 / 8 GPUs.  Each
+    # rank runs its own independent stream (no data-path collective); rank 0 reports the aggregate and the per-rank figures.
+    c3_multi = None
+    if (use_dist and ((world > 1 and not args.no_extras) or args.config3_all_ranks) and args.variant == "v1" and args.weighting == "none"
+            and not args.level_iterations and (W, H, L) == (640, 480, 4)):
+        try:
+            c3 = leg_config3(local_rank, args.iterations, args.streams, max(2, min(args.steps, 10)), seed=1234 + rank)
+            mine = [c3["frame_pairs_per_s"], c3["roofline"]["frac"], c3["roofline"]["avg_launch_us"], float(c3["batch_pairs"])]
+        except Exception:                                                  # a rank whose leg fails still joins the collective
+            c3, mine = None, [float("nan")] * 4
+        tm = torch.tensor(mine, dtype=torch.float64, device="cuda")
+        allc = [torch.zeros_like(tm) for _ in range(world)]
+        dist.all_gather(allc, tm)
+        allc = torch.stack(allc).cpu().numpy()
+        if rank == 0:
+            c3_multi = dict(c3 or {"error": "rank 0 leg failed"})
+            c3_multi.update({"n_gpus": world, "frame_pairs_per_s_per_rank": [float(v) for v in allc[:, 0]],
+                             "frame_pairs_per_s": float(np.nansum(allc[:, 0])) if np.all(np.isfinite(allc[:, 0])) else None,
+                             "roofline_frac_per_rank": [float(v) for v in allc[:, 1]],
+                             "level0_avg_launch_us_per_rank": [float(v) for v in allc[:, 2]],
+                             "aggregate_note": "sum over ranks of independent streams run concurrently (weak scaling); `roofline` is rank 0's"})
     if rank == 0:
+        if c3_multi is not None:
+            out["config3"] = c3_multi
         if extras:
             # the rest of what north_star asks to be reported, on the driver's clock, outside the `value` region and bounded in time
             # (each leg builds and frees its own contexts; a leg that fails reports its error instead of taking the line down)

@@ -69,7 +69,10 @@ def test_bench_through_the_rank_launcher_with_one_rank():
         assert len(lines) == 1
         return json.loads(lines[0])
     plain = run([])
-    spawned = run(["--spawn"])
+    spawned = run(["--spawn", "--config3-all-ranks"])
+    c3 = spawned["config3"]                               # the N > 1 form of the 1280x960 leg: every rank runs it, rank 0 gathers
+    assert c3["n_gpus"] == 1 and len(c3["frame_pairs_per_s_per_rank"]) == 1 and c3["frame_pairs_per_s"] > 0
+    assert 0 < c3["roofline_frac_per_rank"][0] < 1 and c3["level0_avg_launch_us_per_rank"][0] > 0
     assert spawned["n_gpus"] == 1 and spawned["ranks_joined"] == 1 and "world size 1" in spawned["collective"]
     assert spawned["config"]["pose_gather_ms_per_step"] is not None and spawned["config"]["pose_gather_ms_per_step"] >= 0
     pr = spawned["per_rank"]
