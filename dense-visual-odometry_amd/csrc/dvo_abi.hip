@@ -96,6 +96,8 @@ struct dvo_ctx {
     SolveKey last_key;
     bool last_has_init = false;
     int64_t st_fallbacks = 0;            // solves repeated with the three-pass form
+    int64_t st_small_kept = 0;           // k_gn_small: one-pass iterations kept / run again as written (over every fetched solve)
+    int64_t st_small_redone = 0;
     unsigned long long* d_small_stamps = nullptr;   // DVO_SMALL_STAMPS: [max_pairs][8] phase clocks of k_gn_small (diagnostic)
     float* d_rcache = nullptr;           // Student-t device solve: residuals kept between the scale passes [max_pairs][max_w*max_h]
     uint32_t* d_exp_gradh = nullptr;     // DVO_EXP_TAPS side planes [n_slots][exp_plane_texels]: {f16 gx, f16 gy} / intensity
@@ -145,6 +147,7 @@ struct dvo_ctx {
                                         // kernel k_gn_small (0: every level takes the per-iteration launches)
         int small_threads = 0;          // DVO_SMALL_THREADS: workgroup size of k_gn_small (0: chosen from the batch size)
         bool st_exact = false;          // DVO_ST_EXACT: the reference's Student-t always as its three passes (no moment form)
+        bool st_small_exact = false;    // DVO_ST_SMALL_EXACT: ... at the persistent levels only (A/B of k_gn_small's one-pass iterations)
         int exp_taps = 0;               // DVO_EXP_TAPS=1..4: dvo_normal_equations (V1, unweighted) runs an experimental tap
                                         // formulation of the reduction (dvo_exp_taps.inc; tools/exp_taps.py); never the solve path
     } knobs;
@@ -507,6 +510,7 @@ int dvo_create(int device, int max_w, int max_h, int max_levels, int n_slots, in
         ctx->knobs.no_rcache = getenv("DVO_NO_RCACHE") != nullptr;
         ctx->knobs.ingest_unfused = getenv("DVO_INGEST_UNFUSED") != nullptr;
         ctx->knobs.st_exact = getenv("DVO_ST_EXACT") != nullptr;
+        ctx->knobs.st_small_exact = getenv("DVO_ST_SMALL_EXACT") != nullptr;
         if (getenv("DVO_SMALL_STAMPS") != nullptr) {
             CREATE_TRY(hipMalloc((void**)&ctx->d_small_stamps, (size_t)max_pairs * 8 * sizeof(unsigned long long)));
             CREATE_TRY(hipMemset(ctx->d_small_stamps, 0, (size_t)max_pairs * 8 * sizeof(unsigned long long)));
@@ -1105,7 +1109,7 @@ static int record_solve(dvo_ctx* ctx, const SolveKey& k, const float* d_init)
     int rc;
     const double lambda0 = 1.0 / 25.0;                      // TDistributionWeighter: initial_sigma = 5 (t_weighter.py:11-15)
     HIP_TRY(ctx, hipMemsetAsync(ctx->d_irls_done, 0, (size_t)n_pairs * sizeof(int), ctx->stream));
-    if (ctx->d_inexact) HIP_TRY(ctx, hipMemsetAsync(ctx->d_inexact, 0, 4 * sizeof(int), ctx->stream));
+    if (ctx->d_inexact) HIP_TRY(ctx, hipMemsetAsync(ctx->d_inexact, 0, 8 * sizeof(int), ctx->stream));
     HIP_TRY(ctx, dvo_launch_init_state(ctx->d_state, ctx->d_T, d_init, n_pairs, lambda0,
                                        (k.inv_sigma > 0.0 && k.has_last) ? ctx->d_prior : nullptr, ctx->stream));
     // The coarsest levels (at most knobs.small_max_pix pixels each) run in ONE persistent launch, a workgroup per pair
@@ -1146,6 +1150,8 @@ static int record_solve(dvo_ctx* ctx, const SolveKey& k, const float* d_init)
             sp.wparam = ctx->d_wparam;
             sp.rcache = (weight_mode == DVO_WEIGHT_STUDENT_T || weight_mode == DVO_WEIGHT_STUDENT_T_MEAN) ? ctx->d_rcache : nullptr;
             sp.student_t_mean = (weight_mode == DVO_WEIGHT_STUDENT_T_MEAN) ? 1 : 0;
+            sp.st_one_pass = (weight_mode == DVO_WEIGHT_STUDENT_T && !k.st_exact && !ctx->knobs.st_solve_phases && !ctx->knobs.st_small_exact) ? 1 : 0;
+            sp.st_counts = (sp.st_one_pass && ctx->d_inexact) ? ctx->d_inexact + 4 : nullptr;
             sp.rcache_stride = (size_t)ctx->max_w * ctx->max_h;
             sp.tolerance = tolerance;
             sp.max_increased = max_increased_steps_allowed;
@@ -1298,8 +1304,8 @@ int dvo_solve_batch_enqueue(dvo_ctx* ctx, int n_pairs, const int* prev_slot, con
     if (weight_mode == DVO_WEIGHT_STUDENT_T && ctx->d_partials2 == nullptr && !ctx->knobs.st_solve_phases) {
         // moment form of the reference's Student-t: a second set of partial sums and the counter of unsafe iterations
         if (hipMalloc((void**)&ctx->d_partials2, ctx->partials_doubles * sizeof(double)) != hipSuccess ||
-            hipMalloc((void**)&ctx->d_inexact, 4 * sizeof(int)) != hipSuccess ||
-            hipHostMalloc((void**)&ctx->h_inexact, 4 * sizeof(int)) != hipSuccess) {
+            hipMalloc((void**)&ctx->d_inexact, 8 * sizeof(int)) != hipSuccess ||
+            hipHostMalloc((void**)&ctx->h_inexact, 8 * sizeof(int)) != hipSuccess) {
             (void)hipGetLastError();
             if (ctx->d_partials2) (void)hipFree(ctx->d_partials2);
             if (ctx->d_inexact) (void)hipFree(ctx->d_inexact);
@@ -1371,8 +1377,12 @@ int dvo_solve_batch_fetch(dvo_ctx* ctx, int n_pairs, float* T_out, double* xi_ou
     if (xi_out) HIP_TRY(ctx, hipMemcpyAsync(ctx->hs.xi, ctx->d_xi, (size_t)n_pairs * 6 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     if (iters_out) HIP_TRY(ctx, hipMemcpyAsync(ctx->hs.iters, ctx->d_iters, (size_t)n_pairs * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
     if (err_out) HIP_TRY(ctx, hipMemcpyAsync(ctx->hs.err, ctx->d_err, (size_t)n_pairs * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-    if (ctx->last_moment) HIP_TRY(ctx, hipMemcpyAsync(ctx->h_inexact, ctx->d_inexact, 4 * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    if (ctx->last_moment) HIP_TRY(ctx, hipMemcpyAsync(ctx->h_inexact, ctx->d_inexact, 8 * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->last_moment) { ctx->st_small_kept += ctx->h_inexact[4]; ctx->st_small_redone += ctx->h_inexact[5]; }
+    if (ctx->last_moment && getenv("DVO_ST_DEBUG") && ctx->h_inexact[5])
+        fprintf(stderr, "dvo: persistent levels: %d one-pass iterations kept, %d run again (%d for the IRLS shape / series, %d at the coarsest level)\n",
+                ctx->h_inexact[4], ctx->h_inexact[5], ctx->h_inexact[6], ctx->h_inexact[7]);
     if (ctx->last_moment && *ctx->h_inexact != 0) {
         // an iteration of this batch did not meet the moment form's bound (or its IRLS would not take exactly two passes): the same
         // solve again with the reference's passes as written (slot ids and initial poses are still in their device buffers)
@@ -1409,6 +1419,14 @@ int dvo_student_t_fallbacks(const dvo_ctx* ctx, int64_t* count)
 {
     if (!ctx || !count) return DVO_ERR_INVALID_ARG;
     *count = ctx->st_fallbacks;
+    return DVO_OK;
+}
+
+int dvo_student_t_small_level_counts(const dvo_ctx* ctx, int64_t* kept, int64_t* redone)
+{
+    if (!ctx || !kept || !redone) return DVO_ERR_INVALID_ARG;
+    *kept = ctx->st_small_kept;
+    *redone = ctx->st_small_redone;
     return DVO_OK;
 }
 

@@ -158,6 +158,8 @@ struct DvoSmallParams {
     double inv_sigma;
     double lambda0;              // Student-t: 1 / initial_sigma^2
     int student_t_mean;          // Student-t scale = mean (proper) instead of the reference's sum (quirk Q3)
+    int st_one_pass;             // Student-t of the reference: iterations >= 3 of a level in one pass under a predicted lambda (else as written)
+    int* st_counts;              // diagnostic, or null: [0] += one-pass iterations kept, [1] += one-pass iterations run again as written
     int* irls_done;              // unused here (the IRLS loop runs inside the kernel); null
     double* trace;
     int trace_stride, trace_cap;

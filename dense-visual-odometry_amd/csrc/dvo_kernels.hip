@@ -1927,8 +1927,11 @@ __device__ __forceinline__ bool student_t_predicted_combine(double* rec, double 
     const double lam2 = 1.0 / S1;
     ok = ok && (S1 > 0.0) && isfinite(lam2) && (fabs(lam2 - lam1) < 1e-3);
     const double x2 = lam2 * 0.2;
-    const double xmax = fmax(x1, x2) * cbrt(M3);                                        // r^2 <= M3^(1/3)
-    ok = ok && (xmax < 1e-2);                                                           // series of S1 good to xmax^3
+    // r^2 <= M3^(1/3) for every point: with xmax < 1 the two series (S(lambda1) above, sum w r^2 below) alternate with decreasing
+    // terms, so stopping after the M3 term is off by less than the next one, x^3 M4 <= x^3 M3^(4/3): kept below 1e-6 of the sum
+    const double c3 = cbrt(M3);
+    const double xmax = fmax(x1, x2) * c3;
+    ok = ok && (xmax < 0.5) && (xmax * xmax * xmax * c3 <= 1e-6 * M1);
     const int dg[6] = {0, 6, 11, 15, 18, 20};
 #pragma unroll
     for (int k = 0; k < 6; ++k) dbound[k] = 0.24 * fabs(lam_p - lam2) * sqrt(M3 * fmax(rec[dg[k]], 0.0) * (1.0 / 1.2));
@@ -1943,8 +1946,12 @@ template <class P>
 __device__ __forceinline__ void gn_control(const P& p, int phase, int pair, DvoPairState& st, float* T, int* active,
                                            double* wparam, double* rec, double* ws /* [72] LDS workspace */,
                                            const double* rec2 = nullptr, int* inexact = nullptr, double lambda0 = 0.0,
-                                           int predicted = 0)
+                                           int predicted = 0, double lam_known = -1.0)
 {
+    // predicted: 1 = the record was weighted under the predicted lambda in *wparam, unsafe iterations are counted in inexact[0..3]
+    // (k_solve; the host repeats the batch); 2 = the same inside k_gn_small: an unsafe iteration sets *inexact = 1 and returns with
+    // the state untouched (the kernel runs the iteration again as written).  lam_known > 0: the lambda the IRLS loop of this
+    // iteration ended on (k_gn_small's exact path), recorded for the prediction.
     if (phase != 0) {
         // Student-t scale pass k (weighter/t_weighter.py:24-32): lambda <- 1 / scale, stop when lambda has settled.
         //   weight_mode 1 (the reference): scale = SUM of the weighted r^2 (quirk Q3), |d lambda| < 1e-3 absolute
@@ -1991,10 +1998,12 @@ __device__ __forceinline__ void gn_control(const P& p, int phase, int pair, DvoP
         const int dg[6] = {0, 6, 11, 15, 18, 20};
         double dmax = 0.0, imax = 0.0;
         for (int k = 0; k < 6; ++k) { dmax = fmax(dmax, dbound[k] / rec[dg[k]]); imax = fmax(imax, fabs(inc[k])); }
-        if (n > 0.0) {
+        const bool bound_ok = dmax <= (predicted ? 8e-6 : 2e-6) * imax;
+        if (predicted == 2) {
+            if (!(moment_ok && bound_ok)) { *inexact = moment_ok ? 1 : 2; return; }    // (also n == 0: dmax is NaN)
+        } else if (n > 0.0) {
             // inexact[0]: iterations that failed; [1]: the IRLS would not take exactly two passes / series not applicable;
             // [2]: bound of the moment form; [3]: bound of the predicted-lambda form
-            const bool bound_ok = dmax <= (predicted ? 8e-6 : 2e-6) * imax;
             if (!moment_ok) atomicAdd(inexact + 1, 1);
             else if (!bound_ok) atomicAdd(inexact + (predicted ? 3 : 2), 1);
             if (!(moment_ok && bound_ok)) atomicAdd(inexact, 1);
@@ -2038,7 +2047,8 @@ __device__ __forceinline__ void gn_control(const P& p, int phase, int pair, DvoP
     }
     if (stop) { st.active = 0; *active = 0; }
     if (p.weight_mode == 1) { *wparam = 1.0 / 25.0; st.pad = 0; }                       // next iteration restarts IRLS (t_weighter.py:23)
-    if (one_pass) {
+    if (!one_pass && lam_known > 0.0) lam2 = lam_known;
+    if (one_pass || lam_known > 0.0) {
         // lambda of the next iteration's weights (the reduction weighted with a predicted lambda reads it from wparam)
         // (lambda settles geometrically with the pose: the next step of the sequence is the last step times the ratio of the last
         // two, clamped to [0, 1]; on the reference's fixtures that predicts lambda to 6e-5..5e-4 relative, ten times better than a
@@ -2140,20 +2150,22 @@ hipError_t dvo_launch_solve(const DvoSolveParams& p, hipStream_t s)
 #define DVO_SMALL_MAX_THREADS 1024
 #define DVO_SMALL_MAX_WAVES (DVO_SMALL_MAX_THREADS / 64)
 
-// Wave totals (float64) of the DVO_NACC per-lane float32 sums -> out[0..31] (LDS).  Transposed through a wave-private LDS
+// Wave totals (float64) of the NT per-lane float32 sums -> out[0..31] (LDS).  Transposed through a wave-private LDS
 // region eight terms at a time: lane l adds eight of the 64 values of term l & 7 in float64 (conflict-free reads), three
 // shuffles join the eight segments.  Wave-synchronous: no workgroup barrier.
+template <int NT>
 __device__ __forceinline__ void wave_reduce_terms(const float* acc, float* wbuf /* [8][65] */, double* out)
 {
+    static_assert(NT == DVO_NACC || NT == DVO_STRIDE, "30 sums, or 32 with the Student-t moments");
     const int lane = threadIdx.x & 63;
     const int term = lane & 7, seg = lane >> 3;
 #pragma unroll
-    for (int c = 0; c < (DVO_NACC + 7) / 8; ++c) {
+    for (int c = 0; c < (NT + 7) / 8; ++c) {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();                    // loads of the previous chunk are done
 #pragma unroll
         for (int i = 0; i < 8; ++i)
-            if (c * 8 + i < DVO_NACC) wbuf[i * 65 + lane] = acc[c * 8 + i];
+            if (c * 8 + i < NT) wbuf[i * 65 + lane] = acc[c * 8 + i];
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -2164,9 +2176,9 @@ __device__ __forceinline__ void wave_reduce_terms(const float* acc, float* wbuf 
         sgm += __shfl_xor(sgm, 8, 64);
         sgm += __shfl_xor(sgm, 16, 64);
         sgm += __shfl_xor(sgm, 32, 64);
-        if (seg == 0 && c * 8 + term < DVO_NACC) out[c * 8 + term] = sgm;
+        if (seg == 0 && c * 8 + term < NT) out[c * 8 + term] = sgm;
     }
-    if (lane >= DVO_NACC && lane < DVO_STRIDE) out[lane] = 0.0;
+    if (lane >= NT && lane < DVO_STRIDE) out[lane] = 0.0;
 }
 
 // THREADS = the launched workgroup size (256 / 512 / 1024): the launch bound then equals it, so the narrow workgroups of the
@@ -2181,6 +2193,7 @@ __device__ __forceinline__ void gn_small_body(const DvoSmallParams& p)
     __shared__ DvoPairState st;
     __shared__ float T_sh[12];
     __shared__ int active_sh;
+    __shared__ int redo_sh;                 // Student-t: the one-pass form of this iteration was not safe, run it again as written
     __shared__ double wpar_sh;
     __shared__ double rec_sh[DVO_STRIDE];
     __shared__ double wsum[(NWAVES * DVO_STRIDE >= 72) ? NWAVES : 3][DVO_STRIDE];      // (also the 72-double workspace of solve6_pinv)
@@ -2223,6 +2236,7 @@ __device__ __forceinline__ void gn_small_body(const DvoSmallParams& p)
             st.err_prev = DVO_FLT_MAX;
             st.increased = 0;
             st.active = 1;
+            st.lam_n = 0;
             active_sh = 1;
             for (int k = 0; k < 4; ++k) st.oq[k] = st.lq[k];
             for (int k = 0; k < 3; ++k) st.ot[k] = st.lt[k];
@@ -2238,136 +2252,176 @@ __device__ __forceinline__ void gn_small_body(const DvoSmallParams& p)
             for (int i = 0; i < 12; ++i) T[i] = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(T_sh[i])));
             float wpar = 0.0f;
             if constexpr (WMODE == 2) wpar = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint((float)wpar_sh)));
-            if constexpr (WMODE == 1) {
-                // TDistributionWeighter.weight (weighter/t_weighter.py:21-34): lambda <- 1 / scale(lambda) until |d lambda| < 1e-3
-                // student_t_mean (weight_mode 3, "proper"): scale = mean, relative tolerance, at most 4 passes, warm-started from the
-                // previous iteration's lambda; otherwise the reference's loop (sum, |d lambda| < 1e-3, at most 50 passes, from 1/25)
-                const bool mean = p.student_t_mean != 0;
-                const int max_pass = mean ? 4 : 50;
-                double last = mean ? wpar_sh : p.lambda0, cur = last;
-                for (int pass = 0; pass < max_pass; ++pass) {
-                    const float lamf = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint((float)last)));
-                    float sacc = 0.0f, scnt = 0.0f;
-                    for (int seg = rec0; seg < count; seg += gstride) {          // wave-uniform bounds
-                        float r[DVO_PX_PER_THREAD];
-                        if (pass == 0 || rc_mine == nullptr) {
-                            uint2 rc[DVO_PX_PER_THREAD];
-                            PixelGeo geo[DVO_PX_PER_THREAD];
-                            PixelTaps taps[DVO_PX_PER_THREAD];
-#pragma unroll
-                            for (int j = 0; j < DVO_PX_PER_THREAD; ++j) rc[j] = *reinterpret_cast<const uint2*>(list + seg + j * 64 + lane_);
-#pragma unroll
-                            for (int j = 0; j < DVO_PX_PER_THREAD; ++j) {
-                                const bool live = (seg + j * 64 + lane_) < count;
-                                const unsigned pix = rc[j].y;
-                                dvo_geo<SKEW, VARIANT == 3>(g, cam, T, (float)(pix & 0xfffu), (float)((pix >> 12) & 0xfffu), __uint_as_float(rc[j].x), live, geo[j]);
-                                dvo_load_taps(g, packed_cur, geo[j], taps[j]);
-                                taps[j].own = 0u;
-                            }
-#pragma unroll
-                            for (int j = 0; j < DVO_PX_PER_THREAD; ++j) {
-                                r[j] = __builtin_nanf("");
-                                if (geo[j].ok) {
-                                    PixelOut o;
-                                    dvo_finish<VARIANT, false>(cam, geo[j], taps[j], rc[j].y >> 24, o);
-                                    r[j] = o.r;
+            // Student-t of the reference, from the fourth iteration of a level on: ONE pass over the records with the weights under
+            // the lambda predicted from the last three (student_t_predicted_combine: the pass still yields the exact lambda; the
+            // control step bounds what the prediction costs and, if that is not inside the parity bound, leaves the state alone and
+            // the iteration runs again below as the reference writes it).  Workgroup-uniform: st is in LDS, written before a barrier.
+            bool pred = false;
+            // (from 160 x 120 on: over the ~4 k records of an 80 x 60 level the bound is met by one iteration in seven)
+            if constexpr (WMODE == 1) pred = (p.st_one_pass != 0) && (st.lam_n >= 3) && (g.npix >= 160 * 120);
+            double lam_exact = -1.0;
+            for (int attempt = 0; attempt < 2; ++attempt) {
+                if constexpr (WMODE == 1) {
+                    if (pred) {
+                        wpar = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint((float)wpar_sh)));
+                    } else {
+                        // TDistributionWeighter.weight (weighter/t_weighter.py:21-34): lambda <- 1 / scale(lambda) until |d lambda| < 1e-3
+                        // student_t_mean (weight_mode 3, "proper"): scale = mean, relative tolerance, at most 4 passes, warm-started from the
+                        // previous iteration's lambda; otherwise the reference's loop (sum, |d lambda| < 1e-3, at most 50 passes, from 1/25)
+                        const bool mean = p.student_t_mean != 0;
+                        const int max_pass = mean ? 4 : 50;
+                        double last = mean ? wpar_sh : p.lambda0, cur = last;
+                        for (int pass = 0; pass < max_pass; ++pass) {
+                            const float lamf = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint((float)last)));
+                            float sacc = 0.0f, scnt = 0.0f;
+                            for (int seg = rec0; seg < count; seg += gstride) {          // wave-uniform bounds
+                                float r[DVO_PX_PER_THREAD];
+                                if (pass == 0 || rc_mine == nullptr) {
+                                    uint2 rc[DVO_PX_PER_THREAD];
+                                    PixelGeo geo[DVO_PX_PER_THREAD];
+                                    PixelTaps taps[DVO_PX_PER_THREAD];
+        #pragma unroll
+                                    for (int j = 0; j < DVO_PX_PER_THREAD; ++j) rc[j] = *reinterpret_cast<const uint2*>(list + seg + j * 64 + lane_);
+        #pragma unroll
+                                    for (int j = 0; j < DVO_PX_PER_THREAD; ++j) {
+                                        const bool live = (seg + j * 64 + lane_) < count;
+                                        const unsigned pix = rc[j].y;
+                                        dvo_geo<SKEW, VARIANT == 3>(g, cam, T, (float)(pix & 0xfffu), (float)((pix >> 12) & 0xfffu), __uint_as_float(rc[j].x), live, geo[j]);
+                                        dvo_load_taps(g, packed_cur, geo[j], taps[j]);
+                                        taps[j].own = 0u;
+                                    }
+        #pragma unroll
+                                    for (int j = 0; j < DVO_PX_PER_THREAD; ++j) {
+                                        r[j] = __builtin_nanf("");
+                                        if (geo[j].ok) {
+                                            PixelOut o;
+                                            dvo_finish<VARIANT, false>(cam, geo[j], taps[j], rc[j].y >> 24, o);
+                                            r[j] = o.r;
+                                        }
+                                    }
+                                    if (rc_mine != nullptr) {
+        #pragma unroll
+                                        for (int j = 0; j < DVO_PX_PER_THREAD; ++j)
+                                            if (seg + j * 64 + lane_ < count) rc_mine[seg + j * 64 + lane_] = r[j];
+                                    }
+                                } else {
+        #pragma unroll
+                                    for (int j = 0; j < DVO_PX_PER_THREAD; ++j) {
+                                        const int idx = seg + j * 64 + lane_;
+                                        r[j] = (idx < count) ? rc_mine[idx] : __builtin_nanf("");
+                                    }
+                                }
+        #pragma unroll
+                                for (int j = 0; j < DVO_PX_PER_THREAD; ++j) {
+                                    if (r[j] == r[j]) {
+                                        const float r2 = r[j] * r[j];
+                                        sacc += r2 * (6.0f * fast_rcp(fmaf(r2, lamf, 5.0f)));       // t_weighter.py:43-45, dof = 5
+                                        scnt += 1.0f;
+                                    }
                                 }
                             }
-                            if (rc_mine != nullptr) {
-#pragma unroll
-                                for (int j = 0; j < DVO_PX_PER_THREAD; ++j)
-                                    if (seg + j * 64 + lane_ < count) rc_mine[seg + j * 64 + lane_] = r[j];
-                            }
-                        } else {
-#pragma unroll
-                            for (int j = 0; j < DVO_PX_PER_THREAD; ++j) {
-                                const int idx = seg + j * 64 + lane_;
-                                r[j] = (idx < count) ? rc_mine[idx] : __builtin_nanf("");
-                            }
+                            const double sw = wave_sum((double)sacc), cw = wave_sum((double)scnt);
+                            if (lane_ == 0) { scal[pass & 1][wave_] = sw; scnt_sh[pass & 1][wave_] = cw; }
+                            __syncthreads();
+                            double S = 0.0, N = 0.0;
+                            for (int w = 0; w < nwaves; ++w) { S += scal[pass & 1][w]; N += scnt_sh[pass & 1][w]; }   // every thread, same order
+                            cur = mean ? N / S : 1.0 / S;
+                            if (mean ? (fabs(cur - last) <= 1e-3 * cur) : (fabs(cur - last) < 1e-3)) break;      // uniform
+                            last = cur;
                         }
-#pragma unroll
-                        for (int j = 0; j < DVO_PX_PER_THREAD; ++j) {
-                            if (r[j] == r[j]) {
-                                const float r2 = r[j] * r[j];
-                                sacc += r2 * (6.0f * fast_rcp(fmaf(r2, lamf, 5.0f)));       // t_weighter.py:43-45, dof = 5
-                                scnt += 1.0f;
-                            }
-                        }
+                        wpar = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint((float)cur)));
+                        if (mean && tid == 0) wpar_sh = cur;          // (every thread read wpar_sh before the first barrier of the loop)
+                        if (!mean) lam_exact = cur;
+                        stamp(4);
                     }
-                    const double sw = wave_sum((double)sacc), cw = wave_sum((double)scnt);
-                    if (lane_ == 0) { scal[pass & 1][wave_] = sw; scnt_sh[pass & 1][wave_] = cw; }
-                    __syncthreads();
-                    double S = 0.0, N = 0.0;
-                    for (int w = 0; w < nwaves; ++w) { S += scal[pass & 1][w]; N += scnt_sh[pass & 1][w]; }   // every thread, same order
-                    cur = mean ? N / S : 1.0 / S;
-                    if (mean ? (fabs(cur - last) <= 1e-3 * cur) : (fabs(cur - last) < 1e-3)) break;      // uniform
-                    last = cur;
                 }
-                wpar = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint((float)cur)));
-                if (mean && tid == 0) wpar_sh = cur;          // (every thread read wpar_sh before the first barrier of the loop)
-                stamp(4);
-            }
 
-            float acc[DVO_NACC];
+                constexpr int NT = (WMODE == 1) ? DVO_STRIDE : DVO_NACC;     // Student-t: + the moments sum r^4, sum r^6 of the one-pass form
+                const float lam0f = (float)p.lambda0;
+                float acc[NT];
 #pragma unroll
-            for (int i = 0; i < DVO_NACC; ++i) acc[i] = 0.0f;
-            for (int seg = rec0; seg < count; seg += gstride) {                     // wave-uniform bounds
-                uint2 rc[DVO_PX_PER_THREAD];
-                PixelGeo geo[DVO_PX_PER_THREAD];
-                PixelTaps taps[DVO_PX_PER_THREAD];
+                for (int i = 0; i < NT; ++i) acc[i] = 0.0f;
+                for (int seg = rec0; seg < count; seg += gstride) {                     // wave-uniform bounds
+                    uint2 rc[DVO_PX_PER_THREAD];
+                    PixelGeo geo[DVO_PX_PER_THREAD];
+                    PixelTaps taps[DVO_PX_PER_THREAD];
 #pragma unroll
-                for (int j = 0; j < DVO_PX_PER_THREAD; ++j) rc[j] = *reinterpret_cast<const uint2*>(list + seg + j * 64 + lane_);
+                    for (int j = 0; j < DVO_PX_PER_THREAD; ++j) rc[j] = *reinterpret_cast<const uint2*>(list + seg + j * 64 + lane_);
 #pragma unroll
-                for (int j = 0; j < DVO_PX_PER_THREAD; ++j) {
-                    const bool live = (seg + j * 64 + lane_) < count;
-                    const unsigned pix = rc[j].y;
-                    const unsigned xi = pix & 0xfffu, yi = (pix >> 12) & 0xfffu;
-                    dvo_geo<SKEW, VARIANT == 3>(g, cam, T, (float)xi, (float)yi, __uint_as_float(rc[j].x), live, geo[j]);
-                    dvo_load_taps(g, packed_cur, geo[j], taps[j]);
-                    taps[j].own = 0u;
-                    if (VARIANT == 1) taps[j].own = geo[j].ok ? packed_prev[yi * (unsigned)g.pitch + xi] : 0u;
-                }
+                    for (int j = 0; j < DVO_PX_PER_THREAD; ++j) {
+                        const bool live = (seg + j * 64 + lane_) < count;
+                        const unsigned pix = rc[j].y;
+                        const unsigned xi = pix & 0xfffu, yi = (pix >> 12) & 0xfffu;
+                        dvo_geo<SKEW, VARIANT == 3>(g, cam, T, (float)xi, (float)yi, __uint_as_float(rc[j].x), live, geo[j]);
+                        dvo_load_taps(g, packed_cur, geo[j], taps[j]);
+                        taps[j].own = 0u;
+                        if (VARIANT == 1) taps[j].own = geo[j].ok ? packed_prev[yi * (unsigned)g.pitch + xi] : 0u;
+                    }
 #pragma unroll
-                for (int j = 0; j < DVO_PX_PER_THREAD; ++j) {
-                    if (geo[j].ok) {
-                        PixelOut o;
-                        dvo_finish<VARIANT, true>(cam, geo[j], taps[j], rc[j].y >> 24, o);
-                        const float r = o.r;
-                        const float r2 = r * r;
-                        float wt = 1.0f;
-                        if (WMODE == 1) wt = 6.0f * fast_rcp(fmaf(r2, wpar, 5.0f));              // t_weighter.py:34
-                        if (WMODE == 2) { const float ar = fabsf(r); wt = (ar <= wpar) ? 1.0f : wpar * fast_rcp(ar); }
-                        float wj[6];
+                    for (int j = 0; j < DVO_PX_PER_THREAD; ++j) {
+                        if (geo[j].ok) {
+                            PixelOut o;
+                            dvo_finish<VARIANT, true>(cam, geo[j], taps[j], rc[j].y >> 24, o);
+                            const float r = o.r;
+                            const float r2 = r * r;
+                            float wt = 1.0f;
+                            if (WMODE == 1) wt = 6.0f * fast_rcp(fmaf(r2, wpar, 5.0f));              // t_weighter.py:34
+                            if (WMODE == 2) { const float ar = fabsf(r); wt = (ar <= wpar) ? 1.0f : wpar * fast_rcp(ar); }
+                            float wj[6];
 #pragma unroll
-                        for (int k = 0; k < 6; ++k) wj[k] = (WMODE == 0) ? o.J[k] : wt * o.J[k];
-                        int q = 0;
+                            for (int k = 0; k < 6; ++k) wj[k] = (WMODE == 0) ? o.J[k] : wt * o.J[k];
+                            int q = 0;
 #pragma unroll
-                        for (int a = 0; a < 6; ++a)
+                            for (int a = 0; a < 6; ++a)
 #pragma unroll
-                            for (int b = a; b < 6; ++b) { acc[q] = fmaf(wj[a], o.J[b], acc[q]); ++q; }
+                                for (int b = a; b < 6; ++b) { acc[q] = fmaf(wj[a], o.J[b], acc[q]); ++q; }
 #pragma unroll
-                        for (int k = 0; k < 6; ++k) acc[21 + k] = fmaf(wj[k], r, acc[21 + k]);
-                        acc[27] = fmaf((WMODE == 0) ? r : wt * r, r, acc[27]);
-                        acc[28] += 1.0f;
-                        if (WMODE != 0) acc[29] += r2;
+                            for (int k = 0; k < 6; ++k) acc[21 + k] = fmaf(wj[k], r, acc[21 + k]);
+                            if (WMODE == 1 && pred) {
+                                // (as k_reduce's predicted-lambda form) [27]: the first scale pass under the constant lambda0, exact per
+                                // point; [30], [31]: the moments from which the control step rebuilds the second pass
+                                acc[27] += r2 * (6.0f * fast_rcp(fmaf(r2, lam0f, 5.0f)));
+                                const float r4 = r2 * r2;
+                                acc[NT - 2] += r4;
+                                acc[NT - 1] = fmaf(r4, r2, acc[NT - 1]);
+                            } else {
+                                acc[27] = fmaf((WMODE == 0) ? r : wt * r, r, acc[27]);
+                            }
+                            acc[28] += 1.0f;
+                            if (WMODE != 0) acc[29] += r2;
+                        }
                     }
                 }
+                if constexpr (WMODE == 0) acc[DVO_NACC - 1] = acc[DVO_NACC - 3];
+                stamp(0);
+                wave_reduce_terms<NT>(acc, wbuf[wave_], wsum[wave_]);
+                __syncthreads();
+                stamp(1);
+                if (tid < DVO_STRIDE) {
+                    double t = 0.0;
+                    for (int w = 0; w < nwaves; ++w) t += wsum[w][tid];                  // fixed order
+                    rec_sh[tid] = t;
+                }
+                __syncthreads();
+                stamp(2);
+                if (tid == 0) {
+                    redo_sh = 0;
+                    if constexpr (WMODE == 1)
+                        gn_control(p, 0, pair, st, T_sh, &active_sh, &wpar_sh, rec_sh, &wsum[0][0], nullptr, &redo_sh, p.lambda0, pred ? 2 : 0,
+                                   (!pred && p.st_one_pass != 0) ? lam_exact : -1.0);
+                    else
+                        gn_control(p, 0, pair, st, T_sh, &active_sh, &wpar_sh, rec_sh, &wsum[0][0]);
+                    if (WMODE == 1 && p.st_counts != nullptr && pred) {
+                        atomicAdd(p.st_counts + (redo_sh ? 1 : 0), 1);
+                        if (redo_sh == 2) atomicAdd(p.st_counts + 2, 1);
+                        if (redo_sh && li == 0) atomicAdd(p.st_counts + 3, 1);
+                    }
+                }
+                __syncthreads();
+                stamp(3);
+                if (!(WMODE == 1 && pred && redo_sh != 0)) break;          // workgroup-uniform
+                pred = false;
             }
-            if constexpr (WMODE == 0) acc[DVO_NACC - 1] = acc[DVO_NACC - 3];
-            stamp(0);
-            wave_reduce_terms(acc, wbuf[wave_], wsum[wave_]);
-            __syncthreads();
-            stamp(1);
-            if (tid < DVO_STRIDE) {
-                double t = 0.0;
-                for (int w = 0; w < nwaves; ++w) t += wsum[w][tid];                  // fixed order
-                rec_sh[tid] = t;
-            }
-            __syncthreads();
-            stamp(2);
-            if (tid == 0) gn_control(p, 0, pair, st, T_sh, &active_sh, &wpar_sh, rec_sh, &wsum[0][0]);
-            __syncthreads();
-            stamp(3);
         }
         __syncthreads();
     }

@@ -189,7 +189,9 @@ int dvo_residuals_jacobian(dvo_ctx* ctx, int level, int prev_slot, int cur_slot,
  * 160 x 120 pixels run in one persistent launch (a workgroup per pair does all their iterations); finer levels take one
  * reduction launch and one control launch per iteration.
  * Student-t IRLS (weighter/t_weighter.py:21-34): on the persistent levels the reference's loop as written (until
- * |d lambda| < 1e-3, at most 50 passes).  On the finer levels DVO_WEIGHT_STUDENT_T_MEAN runs its at most four passes, and
+ * |d lambda| < 1e-3, at most 50 passes) — for DVO_WEIGHT_STUDENT_T from the fourth iteration of a level on in ONE pass with
+ * the weights under a lambda predicted from the last three, whenever the control step can bound what the prediction costs
+ * inside the parity tolerance; an iteration where it cannot runs again, inside the launch, as written.  On the finer levels DVO_WEIGHT_STUDENT_T_MEAN runs its at most four passes, and
  * DVO_WEIGHT_STUDENT_T the TWO scale passes the reference's loop takes whenever the summed scale exceeds 1000 (any image with
  * more than a few hundred non-zero residuals: lambda is then below 1e-3 after the first pass, so the second difference is
  * too) — at levels of 320 x 240 and more evaluated in ONE pass over the points: the scale sum of the second pass and the
@@ -212,6 +214,9 @@ int dvo_solve_batch_enqueue(dvo_ctx* ctx, int n_pairs, const int* prev_slot, con
 int dvo_solve_batch_fetch(dvo_ctx* ctx, int n_pairs, float* T_out, double* xi_out, int* iters_out, double* err_out);
 /* Diagnostic: number of DVO_WEIGHT_STUDENT_T solves this ctx had to repeat with the three-pass form (see above). */
 int dvo_student_t_fallbacks(const dvo_ctx* ctx, int64_t* count);
+/* Diagnostic: over every DVO_WEIGHT_STUDENT_T solve fetched so far, the iterations of the persistent levels that ran in one pass
+ * (*kept) and those that were run again as written because the bound was not met (*redone). */
+int dvo_student_t_small_level_counts(const dvo_ctx* ctx, int64_t* kept, int64_t* redone);
 
 /* Motion prior of the reference (sigma, base_robust_dvo.py:69-71,:154,:190-194,:217-218) for subsequent
  * dvo_solve_batch calls: H += I/sigma, b += (I/sigma) log(old), err += 0.5 sigma |log(old)|, old <- inc^-1 old, with

@@ -133,6 +133,13 @@ def test_student_t_moment_form_equals_the_three_pass_form(frames, vga_stream, mo
             al = BatchAligner(K, scale, 640, 480, 4, max_pairs=16, max_iterations=10, weighting="student_t_reference")
             out.append(al.align_host(gray[:10], depth[:10]))
             assert al.ctx.student_t_fallbacks() == 0
+            # the 160x120 level inside the persistent kernel: iterations 3.. in one pass under the predicted lambda; an iteration whose
+            # bound is not met is run again as written inside the launch (rare: none on these sequences)
+            kept, redone = al.ctx.student_t_small_level_counts()
+            if exact:
+                assert (kept, redone) == (0, 0)
+            else:
+                assert kept >= 9 * 5 and redone <= kept // 8
             al.close()
         monkeypatch.delenv("DVO_ST_EXACT", raising=False)
         assert np.array_equal(out[0]["iters"], out[1]["iters"])
@@ -154,6 +161,45 @@ def test_student_t_result_does_not_depend_on_the_batch_size(frames):
         al.close()
     assert np.array_equal(res[0]["iters"][:2], res[1]["iters"][:2])
     assert np.max(np.abs(res[0]["xi"][:2] - res[1]["xi"][:2])) < 1e-7
+
+
+def test_student_t_persistent_level_runs_an_unsafe_one_pass_iteration_again_as_written(monkeypatch):
+    """A 160x120 pair solved wholly inside the persistent kernel.  Second frame = first frame with a handful of inverted pixels: the summed
+    scale is small, lambda is not, the one-pass iterations (4th on) cannot be bounded, and each is run again inside the launch as the
+    reference writes it: bit-identical to a context that never tried (DVO_ST_SMALL_EXACT).  On an ordinary pair the one-pass iterations
+    are kept and the pose agrees to 2e-8."""
+    from dvo_amd import synthetic
+    from dvo_amd.batch import BatchAligner
+    st = synthetic.make_stream(2, 160, 120, seed=5)
+    flipped = np.stack([st["gray"][0], st["gray"][0]]).copy()
+    rng = np.random.default_rng(3)
+    ys, xs = rng.integers(10, 110, 12), rng.integers(10, 150, 12)
+    flipped[1, ys, xs] = 255 - flipped[1, ys, xs]
+    same_depth = np.stack([st["depth"][0], st["depth"][0]])
+    # (the ordinary pair: 320x240 in three levels, so that the 160x120 level starts from the pose of the level above it, as it does
+    # in a VGA pyramid; started from the identity, lambda moves too fast for the prediction and its iterations are all run again)
+    st2 = synthetic.make_stream(2, 320, 240, seed=5)
+    for src, gray, depth, unsafe in ((st, flipped, same_depth, True), (st2, st2["gray"], st2["depth"], False)):
+        res, counts = [], []
+        for small_exact in (False, True):
+            monkeypatch.delenv("DVO_ST_SMALL_EXACT", raising=False)
+            if small_exact:
+                monkeypatch.setenv("DVO_ST_SMALL_EXACT", "1")
+            al = BatchAligner(src["K"], src["depth_scale"], gray.shape[2], gray.shape[1], 1 if unsafe else 3, max_pairs=1, max_iterations=10,
+                              max_increased_steps_allowed=10, tolerance=0.0, weighting="student_t_reference")
+            res.append(al.align_host(gray, depth))
+            counts.append(al.ctx.student_t_small_level_counts())
+            assert al.ctx.student_t_fallbacks() == 0
+            al.close()
+        monkeypatch.delenv("DVO_ST_SMALL_EXACT", raising=False)
+        assert counts[1] == (0, 0)
+        assert np.array_equal(res[0]["iters"], res[1]["iters"]) and res[0]["iters"][0] == (10 if unsafe else 30)
+        if unsafe:
+            assert counts[0] == (0, 7), counts
+            assert np.array_equal(res[0]["xi"], res[1]["xi"]) and np.array_equal(res[0]["err"], res[1]["err"])
+        else:
+            assert counts[0][0] >= 5 and sum(counts[0]) == 7, counts
+            assert np.max(np.abs(res[0]["xi"] - res[1]["xi"])) < 2e-8
 
 
 def test_student_t_moment_form_falls_back_when_its_bound_fails():
