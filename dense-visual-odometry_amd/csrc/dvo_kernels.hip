@@ -1942,6 +1942,17 @@ __device__ __forceinline__ bool student_t_predicted_combine(double* rec, double 
     return ok;
 }
 
+// The scalars gn_control reads, for k_gn_small: a copy in LDS filled once per launch.  Read from the kernel arguments they are
+// loop invariants, and so is every float64 value derived from them (1 / inv_sigma, the trace row address, ...): the compiler
+// computes those once, before the level loop, in vector registers (float64 has no scalar form) and keeps them across every
+// record loop of the launch, which at the kernel's register cap means ~100 spilled registers.  LDS reads stay where they are.
+struct DvoControlParams {
+    double tolerance, weight_param, inv_sigma;
+    double* trace;
+    int* irls_done;
+    int max_increased, weight_mode, trace_stride, trace_cap;
+};
+
 template <class P>
 __device__ __forceinline__ void gn_control(const P& p, int phase, int pair, DvoPairState& st, float* T, int* active,
                                            double* wparam, double* rec, double* ws /* [72] LDS workspace */,
@@ -2079,6 +2090,18 @@ __device__ __forceinline__ void gn_control(const P& p, int phase, int pair, DvoP
     }
 }
 
+// The control step of k_gn_small, OUT OF LINE.  Inlined, it sits inside the level and iteration loops of the kernel, and the
+// compiler moves everything loop-invariant in it out of them: the float64 literals of its polynomials (sincos, atan2: ~35
+// register pairs; float64 literals cannot be instruction operands) and what it derives from the parameters - all held in vector
+// registers across every record loop of the launch, i.e. spilled to scratch at the kernel's register cap and loaded back one by
+// one on every iteration.  As a function it has no enclosing loop: the literals are built where they are used.
+__device__ __noinline__ void gn_control_small(const DvoControlParams* ctl, int pair, DvoPairState* st, float* T, int* active,
+                                              double* wparam, double* rec, double* ws, int* redo, double lambda0, int predicted,
+                                              double lam_known)
+{
+    gn_control(*ctl, 0, pair, *st, T, active, wparam, rec, ws, nullptr, redo, lambda0, predicted, lam_known);
+}
+
 // rec[0..31] (LDS) = the pair's per-workgroup partials summed by one wave in sum_partials_block's order (see k_solve)
 __device__ __forceinline__ void solve_sum_partials(const double* __restrict__ part, int nblk, double* rec, double (*tmp)[DVO_STRIDE])
 {
@@ -2194,6 +2217,7 @@ __device__ __forceinline__ void gn_small_body(const DvoSmallParams& p)
     __shared__ float T_sh[12];
     __shared__ int active_sh;
     __shared__ int redo_sh;                 // Student-t: the one-pass form of this iteration was not safe, run it again as written
+    __shared__ DvoControlParams ctl;
     __shared__ double wpar_sh;
     __shared__ double rec_sh[DVO_STRIDE];
     __shared__ double wsum[(NWAVES * DVO_STRIDE >= 72) ? NWAVES : 3][DVO_STRIDE];      // (also the 72-double workspace of solve6_pinv)
@@ -2203,7 +2227,13 @@ __device__ __forceinline__ void gn_small_body(const DvoSmallParams& p)
     const int pair = blockIdx.x, tid = threadIdx.x;
     const int lane_ = tid & 63, wave_ = tid >> 6;
     constexpr int nwaves = NWAVES;
-    if (tid == 0) { st = p.state[pair]; active_sh = 1; wpar_sh = p.wparam[pair]; }
+    if (tid == 0) {
+        st = p.state[pair]; active_sh = 1; wpar_sh = p.wparam[pair];
+        ctl.tolerance = p.tolerance; ctl.weight_param = p.weight_param; ctl.inv_sigma = p.inv_sigma;
+        ctl.trace = p.trace; ctl.irls_done = nullptr;
+        ctl.max_increased = p.max_increased; ctl.weight_mode = p.weight_mode;
+        ctl.trace_stride = p.trace_stride; ctl.trace_cap = p.trace_cap;
+    }
     if (tid < 12) T_sh[tid] = p.T[(size_t)pair * 12 + tid];
     const int prev_id = p.prev_slot[pair];
     const uint8_t* prev = p.slots + (size_t)prev_id * p.slot_stride;
@@ -2406,11 +2436,15 @@ __device__ __forceinline__ void gn_small_body(const DvoSmallParams& p)
                 stamp(2);
                 if (tid == 0) {
                     redo_sh = 0;
-                    if constexpr (WMODE == 1)
-                        gn_control(p, 0, pair, st, T_sh, &active_sh, &wpar_sh, rec_sh, &wsum[0][0], nullptr, &redo_sh, p.lambda0, pred ? 2 : 0,
-                                   (!pred && p.st_one_pass != 0) ? lam_exact : -1.0);
+                    // (out of line under the 168-register cap of the narrow workgroups; under the 128 of the 1024-thread workgroup the
+                    // function itself would spill, inside its call frame, more than the inlined step does: 347 -> 1131 us)
+                    const double lam_known = (WMODE == 1 && !pred && p.st_one_pass != 0) ? lam_exact : -1.0;
+                    if constexpr (THREADS == DVO_SMALL_MAX_THREADS)
+                        gn_control(ctl, 0, pair, st, T_sh, &active_sh, &wpar_sh, rec_sh, &wsum[0][0], nullptr, (WMODE == 1) ? &redo_sh : nullptr,
+                                   p.lambda0, (WMODE == 1 && pred) ? 2 : 0, lam_known);
                     else
-                        gn_control(p, 0, pair, st, T_sh, &active_sh, &wpar_sh, rec_sh, &wsum[0][0]);
+                        gn_control_small(&ctl, pair, &st, T_sh, &active_sh, &wpar_sh, rec_sh, &wsum[0][0], (WMODE == 1) ? &redo_sh : nullptr,
+                                         p.lambda0, (WMODE == 1 && pred) ? 2 : 0, lam_known);
                     if (WMODE == 1 && p.st_counts != nullptr && pred) {
                         atomicAdd(p.st_counts + (redo_sh ? 1 : 0), 1);
                         if (redo_sh == 2) atomicAdd(p.st_counts + 2, 1);
