@@ -210,6 +210,21 @@ def timed_steps(fn, sync, steps, warmup=1):
     return (time.perf_counter() - t0) / steps, out
 
 
+def timed_windows(al, d_gray, d_depth, n_frames, sync, steps, warmup=1):
+    """`steps` windows through StreamedAligner.submit_device / drain (a slice's next window is enqueued when its previous result
+    has been fetched: no drain of the GPU between steps), every result fetched inside the timed region.  -> (s per step, last result)"""
+    for _ in range(warmup):
+        al.submit_device(d_gray, d_depth, n_frames)
+    al.drain()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        al.submit_device(d_gray, d_depth, n_frames)
+    out = al.drain()
+    sync()
+    return (time.perf_counter() - t0) / steps, out
+
+
 def leg_student_t(st, gray, depth, B, W, H, L, iterations, streams, device, steps):
     """The reference's own robust mode (use_weighter=True: TDistributionWeighter, weighter/t_weighter.py:21-47) on the metric's
     workload: same stream, same batch, device solve."""
@@ -221,7 +236,7 @@ def leg_student_t(st, gray, depth, B, W, H, L, iterations, streams, device, step
         def sync():
             al.synchronize()
             torch.cuda.synchronize()
-        dt, res = timed_steps(lambda: al.align_device(gray.data_ptr(), depth.data_ptr(), B + 1), sync, steps)
+        dt, res = timed_windows(al, gray.data_ptr(), depth.data_ptr(), B + 1, sync, steps)
     finally:
         al.close()
     return {"frame_pairs_per_s": B / dt, "ms_per_step": 1e3 * dt, "steps": steps, "batch_pairs": B,
@@ -285,7 +300,7 @@ def leg_config3(device, iterations, streams, steps, seed=1234):
             def sync():
                 al.synchronize()
                 torch.cuda.synchronize()
-            dt, res = timed_steps(lambda: al.align_device(gray.data_ptr(), depth.data_ptr(), B + 1), sync, steps)
+            dt, res = timed_windows(al, gray.data_ptr(), depth.data_ptr(), B + 1, sync, steps)
             part = al.parts[0]
             npr = min(B, part.max_pairs)
             launches, ms = roofline_leg(part, gray.data_ptr(), depth.data_ptr(), npr, 2)
@@ -397,18 +412,28 @@ def main():
 
     gather_s = [0.0]
 
-    def step():
-        res = al.align_device(gray.data_ptr(), depth.data_ptr(), n_frames)
-        if use_dist:
+    def share(res):
+        if use_dist and res is not None:
             tg = time.perf_counter()
-            allrec = gather(pose_records(res["T"], res["iters"], res["err"]))       # every rank ends the step with all poses
+            allrec = gather(pose_records(res["T"], res["iters"], res["err"]))       # every rank ends up with all poses of the step
             gather_s[0] += time.perf_counter() - tg
             assert allrec.shape[0] == B * world
         return res
 
+    # A step = ingest + solve of one window of B pairs.  The windows are pipelined (StreamedAligner.submit_device): each of the
+    # `streams` slices of a window is enqueued as soon as the slice's previous result has been fetched, so the GPU does not drain
+    # between steps; step() returns (and, for N > 1, all-gathers) the result of the PREVIOUS step, finish() that of the last one:
+    # K steps = K windows solved, K results fetched and K gathers, all inside the timed region.
+    def step():
+        return share(al.submit_device(gray.data_ptr(), depth.data_ptr(), n_frames))
+
+    def finish():
+        return share(al.drain())
+
     for _ in range(args.warmup):
-        res = step()
-    if not np.all(np.isfinite(res["xi"])):
+        step()
+    res = finish()
+    if res is not None and not np.all(np.isfinite(res["xi"])):
         raise SystemExit("non-finite poses in warm-up")
 
     def fence():
@@ -421,10 +446,18 @@ def main():
     gather_s[0] = 0.0
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        res = step()
+        step()
+    res = finish()
     fence()
     elapsed = time.perf_counter() - t0
     elapsed_rank = elapsed
+    # the same steps with a fetch of every slice at the end of each (the GPU drains between steps): reported beside `value`
+    sync_steps = max(1, min(args.steps, 10))
+    ts0 = time.perf_counter()
+    for _ in range(sync_steps):
+        al.align_device(gray.data_ptr(), depth.data_ptr(), n_frames)
+    fence()
+    step_synchronous_ms = 1e3 * (time.perf_counter() - ts0) / sync_steps
     if use_dist:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -460,10 +493,12 @@ def main():
             a.ctx.set_level_iterations(sched)
         gn_steps = max(1, min(args.steps, 10))
         step()
+        finish()
         fence()
         tg0 = time.perf_counter()
         for _ in range(gn_steps):
-            res_gn = step()
+            step()
+        res_gn = finish()
         fence()
         tg = time.perf_counter() - tg0
         gn_mode = {"variant": "gn (DVO_VARIANT_GN: V1 with the Sobel response normalised and J_w at the warped point; build-defined, "
@@ -501,6 +536,10 @@ def main():
                                    "inside the timed region), weighting=%s, variant=%s%s" % (W, H, L, args.iterations, B, args.weighting, args.variant,
                                                                                           (", iterations per level (finest first) " + args.level_iterations) if args.level_iterations else ""),
                        "batch_pairs_per_gpu": B, "streams_per_gpu": args.streams, "distinct_frames": int(min(n_distinct, n_frames)),
+                       "stepping": "pipelined: a slice's next window is enqueued when its previous result has been fetched; every result "
+                                   "of the K steps is fetched inside the timed region",
+                       "step_synchronous": {"ms_per_step": step_synchronous_ms, "frame_pairs_per_s": world * B / (1e-3 * step_synchronous_ms),
+                                            "steps": sync_steps, "note": "this rank's time with all slices fetched at the end of every step"},
                        "gn_iterations_per_pair": iters_total / B,
                        "gn_iterations_per_s": world * iters_total * args.steps / elapsed,
                        "pose_gather_ms_per_step": (1e3 * gather_s[0] / args.steps) if use_dist else None,

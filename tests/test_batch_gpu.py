@@ -278,6 +278,33 @@ def test_batched_host_upload_and_streamed_aligner(vga_stream):
     np.testing.assert_allclose(r1["xi"], r0["xi"], rtol=0, atol=1e-9)
 
 
+def test_pipelined_windows_equal_window_by_window_alignment(vga_stream):
+    """StreamedAligner.submit_device / drain (a slice's next window enqueued behind the fetch of its previous result, no drain of the GPU
+    between windows) returns, one call later, exactly what align_device returns for the same window - also when consecutive windows hold
+    different frames - and refuses a change of window size with a window in flight."""
+    import torch
+    from dvo_amd.batch import StreamedAligner
+    n = 9
+    g0 = torch.as_tensor(vga_stream["gray"][:n]).cuda().contiguous()
+    d0 = torch.as_tensor(vga_stream["depth"][:n].view(np.int16)).cuda().contiguous()
+    g1, d1 = torch.flip(g0, dims=[0]).contiguous(), torch.flip(d0, dims=[0]).contiguous()      # the same frames played backwards
+    al = StreamedAligner(vga_stream["K"], vga_stream["depth_scale"], 640, 480, 4, max_pairs=n - 1, n_streams=3, max_iterations=4)
+    try:
+        want = [al.align_device(g.data_ptr(), d.data_ptr(), n) for g, d in ((g0, d0), (g1, d1), (g0, d0))]
+        assert al.drain() is None
+        got = [al.submit_device(g.data_ptr(), d.data_ptr(), n) for g, d in ((g0, d0), (g1, d1), (g0, d0))]
+        with pytest.raises(ValueError):
+            al.submit_device(g0.data_ptr(), d0.data_ptr(), n - 2)
+        got.append(al.drain())
+        assert got[0] is None and al.drain() is None
+        for w, g in zip(want, got[1:]):
+            for k in ("T", "xi", "iters", "err"):
+                assert np.array_equal(w[k], g[k]), k
+        assert not np.array_equal(want[0]["xi"], want[1]["xi"])
+    finally:
+        al.close()
+
+
 def test_rccl_pose_gather_through_the_c_abi():
     """dvo_comm_* (RCCL via dlopen): world of one rank on the test box — unique id, communicator, all-gather."""
     from dvo_amd import _cabi
