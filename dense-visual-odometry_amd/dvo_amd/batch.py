@@ -110,10 +110,14 @@ class StreamedAligner:
         self.parts = [BatchAligner(K, depth_scale, width, height, levels, max_pairs=per, device=device, **kw)
                       for _ in range(n_streams)]
         self.ctx = self.parts[0].ctx
+        self._inflight = None                      # slices of the window submit_device left on the GPU
         for a in self.parts:                       # host uploads of all slices take turns on one in-order copy stream
             a.ctx.set_upload_peer(self.ctx)
 
     def close(self):
+        if self._inflight is not None:             # a window still in flight: wait for it before its buffers go away
+            self._inflight = None
+            self.synchronize()
         for a in reversed(self.parts):             # parts[0] owns the shared copy stream: closed last
             a.close()
 
@@ -144,7 +148,7 @@ class StreamedAligner:
         drain() returns the last one.  Windows in flight must not change size between submit_device calls without a drain()."""
         npx = self.width * self.height
         sl = self._slices(n_frames)
-        prev = getattr(self, "_inflight", None)
+        prev = self._inflight
         if prev is not None and [(lo, hi) for _, lo, hi in prev] != [(lo, hi) for _, lo, hi in sl]:
             raise ValueError("window size changed with a window in flight: call drain() first")
         res = []
@@ -158,8 +162,7 @@ class StreamedAligner:
 
     def drain(self):
         """Result of the window submit_device left in flight (None if there is none)."""
-        sl = getattr(self, "_inflight", None)
-        self._inflight = None
+        sl, self._inflight = self._inflight, None
         if sl is None:
             return None
         res = [a.solve_fetch(hi - lo + 1) for a, lo, hi in sl]
