@@ -2369,8 +2369,12 @@ __device__ __forceinline__ void gn_small_body(const DvoSmallParams& p)
                 constexpr int NT = (WMODE == 1) ? DVO_STRIDE : DVO_NACC;     // Student-t: + the moments sum r^4, sum r^6 of the one-pass form
                 const float lam0f = (float)p.lambda0;
                 float acc[NT];
+                // (an opaque zero: from the literal the compiler keeps a block of NT zeroed registers alive through the whole
+                // iteration loop to copy from, and stores / reloads it around the control call)
+                float zero = 0.0f;
+                asm volatile("" : "+v"(zero));
 #pragma unroll
-                for (int i = 0; i < NT; ++i) acc[i] = 0.0f;
+                for (int i = 0; i < NT; ++i) acc[i] = zero;
                 for (int seg = rec0; seg < count; seg += gstride) {                     // wave-uniform bounds
                     uint2 rc[DVO_PX_PER_THREAD];
                     PixelGeo geo[DVO_PX_PER_THREAD];
