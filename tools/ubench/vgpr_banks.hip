@@ -1,5 +1,5 @@
 // Micro-benchmark: does the VGPR bank of a VALU instruction's source operands change its issue cost on gfx950?
-// 16 independent v_fma_f32 per iteration with explicit registers (accumulators v0..v15), 1..8 waves per SIMD, cycles by s_memtime (the
+// 16 independent v_fma_f32 per iteration with explicit registers (accumulators v0..v15), 4 or 8 waves per SIMD (one or two 1024-thread workgroups per CU), cycles by s_memtime (the
 // shader clock itself, not wall time x nominal clock).  Cases: sources in three different banks / two in one bank / three in one bank
 // (bank = register number mod 4), and the same for v_mul_f32 / v_add_f32 (two sources).
 // Build: hipcc --offload-arch=gfx950 -O3 -o vgpr_banks vgpr_banks.hip
@@ -15,6 +15,14 @@
 #define ADD(d, a, b) "v_add_f32 v" #d ", v" #a ", v" #d "\n"
 #define CVT(d, a, b) "v_cvt_f32_i32 v" #d ", v" #d "\n"
 #define FMK(d, a, b) "v_fmac_f32 v" #d ", v" #a ", v" #b "\n"
+// the same operations in the 8-byte VOP3 encoding (the compiler emits the 4-byte VOP2 form whenever the operands allow it)
+#define MUL64(d, a, b) "v_mul_f32_e64 v" #d ", v" #a ", v" #d "\n"
+#define ADD64(d, a, b) "v_add_f32_e64 v" #d ", v" #a ", v" #d "\n"
+#define FMK64(d, a, b) "v_fmac_f32_e64 v" #d ", v" #a ", v" #b "\n"
+#define MULF(d, a, b) "v_fma_f32 v" #d ", v" #a ", v" #d ", 0\n"
+#define CVT64(d, a, b) "v_cvt_f32_i32_e64 v" #d ", v" #d "\n"
+// out of place: destination differs from the sources (dst d, sources a and d+16)
+#define MULO(d, a, b) "v_mul_f32 v" #d ", v" #a ", v41\n"
 // 16 instructions, accumulators 0..15 in order (banks 0,1,2,3,0,...)
 #define SEQ_ALL(X, a, b) X(0,a,b) X(1,a,b) X(2,a,b) X(3,a,b) X(4,a,b) X(5,a,b) X(6,a,b) X(7,a,b) X(8,a,b) X(9,a,b) X(10,a,b) X(11,a,b) X(12,a,b) X(13,a,b) X(14,a,b) X(15,a,b)
 // 16 instructions, accumulators of bank 0 only (0,4,8,12 four times)
@@ -23,7 +31,7 @@
 #define SEQ_B23(X, a, b) X(2,a,b) X(3,a,b) X(6,a,b) X(7,a,b) X(10,a,b) X(11,a,b) X(14,a,b) X(15,a,b) X(2,a,b) X(3,a,b) X(6,a,b) X(7,a,b) X(10,a,b) X(11,a,b) X(14,a,b) X(15,a,b)
 
 template <int CASE>
-__global__ __launch_bounds__(256) void k(unsigned long long* cyc, float* sink, int n)
+__global__ __launch_bounds__(1024) void k(unsigned long long* cyc, float* sink, int n)
 {
     asm volatile("v_mov_b32 v40, 1.0\n v_mov_b32 v41, 0.5\n v_mov_b32 v44, 0.25\n v_mov_b32 v45, 2.0\n v_mov_b32 v48, 1.0\n v_mov_b32 v52, 0.5\n"
                  "v_mov_b32 v0, 0\n v_mov_b32 v1, 0\n v_mov_b32 v2, 0\n v_mov_b32 v3, 0\n v_mov_b32 v4, 0\n v_mov_b32 v5, 0\n v_mov_b32 v6, 0\n v_mov_b32 v7, 0\n"
@@ -42,23 +50,29 @@ __global__ __launch_bounds__(256) void k(unsigned long long* cyc, float* sink, i
         if (CASE == 9) asm volatile(SEQ_ALL(CVT, 40, 41) ::: CLOB);       // cvt (one source)
         if (CASE == 10) asm volatile(SEQ_B23(FMK, 40, 41) ::: CLOB);      // fmac (VOP2 encoding): different banks
         if (CASE == 11) asm volatile(SEQ_B0(FMK, 40, 44) ::: CLOB);       // fmac: all three bank 0
+        if (CASE == 12) asm volatile(SEQ_B23(MUL64, 40, 41) ::: CLOB);
+        if (CASE == 13) asm volatile(SEQ_B23(ADD64, 40, 41) ::: CLOB);
+        if (CASE == 14) asm volatile(SEQ_B23(FMK64, 40, 41) ::: CLOB);
+        if (CASE == 15) asm volatile(SEQ_B23(MULF, 40, 41) ::: CLOB);
+        if (CASE == 16) asm volatile(SEQ_ALL(CVT64, 40, 41) ::: CLOB);
+        if (CASE == 17) asm volatile(SEQ_B23(MULO, 40, 41) ::: CLOB);
     }
     const unsigned long long t1 = __builtin_amdgcn_s_memtime();
     float s;
     asm volatile("v_add_f32 %0, v0, v1\n v_add_f32 %0, %0, v2\n v_add_f32 %0, %0, v3\n v_add_f32 %0, %0, v4\n v_add_f32 %0, %0, v8\n v_add_f32 %0, %0, v12" : "=v"(s) :: CLOB);
     if (threadIdx.x == 0) cyc[blockIdx.x] = t1 - t0;
-    sink[blockIdx.x * 256 + threadIdx.x] = s;
+    sink[blockIdx.x * 1024 + threadIdx.x] = s;
 }
 
 template <int CASE>
 static int run(const char* name, int cus, int waves, unsigned long long* d_cyc, float* d_sink, int n)
 {
-    const int blocks = cus * waves;                  // `waves` workgroups of 256 threads per CU = `waves` waves per SIMD
-    hipLaunchKernelGGL(k<CASE>, dim3(blocks), dim3(256), 0, 0, d_cyc, d_sink, 16);
+    const int blocks = cus * (waves / 4);            // 1024-thread workgroups (4 waves per SIMD each): one or two per CU, evenly placed
+    hipLaunchKernelGGL(k<CASE>, dim3(blocks), dim3(1024), 0, 0, d_cyc, d_sink, 16);
     hipEvent_t e0, e1;
     CHK(hipEventCreate(&e0)); CHK(hipEventCreate(&e1));
     CHK(hipEventRecord(e0, 0));
-    hipLaunchKernelGGL(k<CASE>, dim3(blocks), dim3(256), 0, 0, d_cyc, d_sink, n);
+    hipLaunchKernelGGL(k<CASE>, dim3(blocks), dim3(1024), 0, 0, d_cyc, d_sink, n);
     CHK(hipEventRecord(e1, 0));
     CHK(hipDeviceSynchronize());
     float ms = 0;
@@ -84,9 +98,9 @@ int main()
     unsigned long long* d_cyc;
     float* d_sink;
     CHK(hipMalloc(&d_cyc, sizeof(unsigned long long) * cus * 8));
-    CHK(hipMalloc(&d_sink, sizeof(float) * cus * 8 * 256));
+    CHK(hipMalloc(&d_sink, sizeof(float) * cus * 8 * 1024));
     const int n = 20000;
-    for (int waves : {1, 2, 5, 8}) {
+    for (int waves : {4, 8, 4, 8}) {
         if (run<0>("v_fma_f32 sources in three banks", cus, waves, d_cyc, d_sink, n)) return 1;
         if (run<1>("v_fma_f32 src0, src1 in one bank", cus, waves, d_cyc, d_sink, n)) return 1;
         if (run<2>("v_fma_f32 src0 and accumulator in one bank", cus, waves, d_cyc, d_sink, n)) return 1;
@@ -99,6 +113,12 @@ int main()
         if (run<9>("v_cvt_f32_i32", cus, waves, d_cyc, d_sink, n)) return 1;
         if (run<10>("v_fmac_f32 (VOP2) three banks", cus, waves, d_cyc, d_sink, n)) return 1;
         if (run<11>("v_fmac_f32 (VOP2) one bank", cus, waves, d_cyc, d_sink, n)) return 1;
+        if (run<12>("v_mul_f32_e64 (VOP3 encoding)", cus, waves, d_cyc, d_sink, n)) return 1;
+        if (run<13>("v_add_f32_e64 (VOP3 encoding)", cus, waves, d_cyc, d_sink, n)) return 1;
+        if (run<14>("v_fmac_f32_e64 (VOP3 encoding) three banks", cus, waves, d_cyc, d_sink, n)) return 1;
+        if (run<15>("v_fma_f32 d, a, d, 0 (a multiply as an FMA)", cus, waves, d_cyc, d_sink, n)) return 1;
+        if (run<16>("v_cvt_f32_i32_e64 (VOP3 encoding)", cus, waves, d_cyc, d_sink, n)) return 1;
+        if (run<17>("v_mul_f32 d, a, b (VOP2, destination not a source)", cus, waves, d_cyc, d_sink, n)) return 1;
     }
     return 0;
 }
