@@ -23,6 +23,8 @@
 #define CVT64(d, a, b) "v_cvt_f32_i32_e64 v" #d ", v" #d "\n"
 // out of place: destination differs from the sources (dst d, sources a and d+16)
 #define MULO(d, a, b) "v_mul_f32 v" #d ", v" #a ", v41\n"
+// the VOP2 FMA with its first multiplicand routed through the DPP network (identity permutation)
+#define FMKD(d, a, b) "v_fmac_f32_dpp v" #d ", v" #a ", v" #b " quad_perm:[0,1,2,3] row_mask:0xf bank_mask:0xf\n"
 // 16 instructions, accumulators 0..15 in order (banks 0,1,2,3,0,...)
 #define SEQ_ALL(X, a, b) X(0,a,b) X(1,a,b) X(2,a,b) X(3,a,b) X(4,a,b) X(5,a,b) X(6,a,b) X(7,a,b) X(8,a,b) X(9,a,b) X(10,a,b) X(11,a,b) X(12,a,b) X(13,a,b) X(14,a,b) X(15,a,b)
 // 16 instructions, accumulators of bank 0 only (0,4,8,12 four times)
@@ -56,6 +58,11 @@ __global__ __launch_bounds__(1024) void k(unsigned long long* cyc, float* sink, 
         if (CASE == 15) asm volatile(SEQ_B23(MULF, 40, 41) ::: CLOB);
         if (CASE == 16) asm volatile(SEQ_ALL(CVT64, 40, 41) ::: CLOB);
         if (CASE == 17) asm volatile(SEQ_B23(MULO, 40, 41) ::: CLOB);
+        if (CASE == 18) asm volatile(SEQ_B23(FMA, 40, 40) ::: CLOB);      // a square: both multiplicands the SAME register
+        if (CASE == 19) asm volatile(SEQ_B23(FMKD, 40, 41) ::: CLOB);     // dpp fmac, different banks
+        if (CASE == 20) asm volatile(SEQ_B23(FMKD, 40, 40) ::: CLOB);     // dpp fmac, a square
+        if (CASE == 21) asm volatile(SEQ_B23(FMKD, 40, 44) ::: CLOB);     // dpp fmac, multiplicands in one bank
+        if (CASE == 22) asm volatile(SEQ_B23(FMK, 40, 40) ::: CLOB);      // VOP2 fmac, a square
     }
     const unsigned long long t1 = __builtin_amdgcn_s_memtime();
     float s;
@@ -119,6 +126,11 @@ int main()
         if (run<15>("v_fma_f32 d, a, d, 0 (a multiply as an FMA)", cus, waves, d_cyc, d_sink, n)) return 1;
         if (run<16>("v_cvt_f32_i32_e64 (VOP3 encoding)", cus, waves, d_cyc, d_sink, n)) return 1;
         if (run<17>("v_mul_f32 d, a, b (VOP2, destination not a source)", cus, waves, d_cyc, d_sink, n)) return 1;
+        if (run<18>("v_fma_f32 d, a, a, d (both multiplicands one register)", cus, waves, d_cyc, d_sink, n)) return 1;
+        if (run<19>("v_fmac_f32_dpp identity, different banks", cus, waves, d_cyc, d_sink, n)) return 1;
+        if (run<20>("v_fmac_f32_dpp identity, a square", cus, waves, d_cyc, d_sink, n)) return 1;
+        if (run<21>("v_fmac_f32_dpp identity, multiplicands in one bank", cus, waves, d_cyc, d_sink, n)) return 1;
+        if (run<22>("v_fmac_f32 (VOP2), a square", cus, waves, d_cyc, d_sink, n)) return 1;
     }
     return 0;
 }
