@@ -23,6 +23,10 @@ def test_bench_json_contract():
     assert d["n_gpus"] == 1 and d["steps"] == 2 and d["warmup"] == 1 and d["higher_is_better"] is True
     assert d["scaling"] == "weak" and d["vs_baseline"] is None and d["data"] == "synthetic" and d["unit"] == "frame-pairs/s"
     assert "workload" in d["config"] and "model" not in d["config"]
+    # the timed steps are pipelined windows; the step-synchronous time of the same steps is reported beside them and is not `value`
+    ss = d["config"]["step_synchronous"]
+    assert "pipelined" in d["config"]["stepping"] and ss["ms_per_step"] > 0 and ss["frame_pairs_per_s"] > 0
+    assert abs(d["value"] - 16 / (1e-3 * d["ms_per_step"])) < 1e-6 * d["value"]
     r = d["roofline"]
     for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
         assert k in r, k
