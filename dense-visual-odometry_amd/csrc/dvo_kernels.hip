@@ -13,11 +13,14 @@
 //   k_sum_partials     K4  deterministic fixed-order sum of the per-workgroup partials
 //   k_dense<...>       K5  dense r / J / valid / uv writer (return contract of compute_residuals_and_jacobian)
 //   k_init_state, k_level_begin, k_solve, k_finish   device-side Gauss-Newton control (base_robust_dvo.py:152-232)
-//   k_gn_small<...>        every iteration of the coarse levels of one pair in one persistent workgroup (reduction + control)
+//   k_gn_small_256 / _512 / _1024<...>  every iteration of the coarse levels of one pair in one persistent workgroup (reduction +
+//                          control; the narrow workgroups call the control step out of line: gn_control_small)
 //   k_ingest_level_fused<TW>  one pass per level: planes, Sobel + pack, next level's median pyramid, valid-pixel counts
 //   k_list_scan, k_list_build  valid-point lists (records {z, x | y | I} of the pixels with depth != 0, raster order)
 //   k_batch_bgr_ingest     batched colour conversion + depth clamp in front of the level-0 pass
 //
+// Template parameter WMODE of k_reduce / k_gn_small: 0 no weight, 1 Student-t with the lambda of wparam, 2 Huber; k_reduce only, the
+// reference's Student-t in one pass per iteration: 4 moment form (second set of sums), 5 weights under a predicted lambda.
 // Template parameter VARIANT: 0 = V1 (reference CPU default), 1 = V2 (approximate_image2_gradient), 2 = V3 (numba.cuda kernel
 // semantics), 3 = GN (build-defined: V1 with the gradient normalised and J_w at the warped point).
 //
