@@ -2097,7 +2097,8 @@ __device__ __forceinline__ void gn_control(const P& p, int phase, int pair, DvoP
 // compiler moves everything loop-invariant in it out of them: the float64 literals of its polynomials (sincos, atan2: ~35
 // register pairs; float64 literals cannot be instruction operands) and what it derives from the parameters - all held in vector
 // registers across every record loop of the launch, i.e. spilled to scratch at the kernel's register cap and loaded back one by
-// one on every iteration.  As a function it has no enclosing loop: the literals are built where they are used.
+// one on every iteration.  As a function it has no enclosing loop: the literals are built where they are used; what its ~165 live
+// registers cost under the kernel's 128-register cap is spilled inside its own frame, by one lane.
 __device__ __noinline__ void gn_control_small(const DvoControlParams* ctl, int pair, DvoPairState* st, float* T, int* active,
                                               double* wparam, double* rec, double* ws, int* redo, double lambda0, int predicted,
                                               double lam_known)
@@ -2207,9 +2208,7 @@ __device__ __forceinline__ void wave_reduce_terms(const float* acc, float* wbuf 
     if (lane >= NT && lane < DVO_STRIDE) out[lane] = 0.0;
 }
 
-// THREADS = the launched workgroup size (256 / 512 / 1024): the launch bound then equals it, so the narrow workgroups of the
-// large-batch case are not held to the 128 registers a 1024-thread workgroup allows (the one-lane float64 control step needs
-// ~160 live registers at its peak; under the 128 cap it spilled 82-112 of them into scratch on every iteration).
+// THREADS = the launched workgroup size (256 / 512 / 1024): sizes the LDS arrays and the loop strides for that shape.
 template <int VARIANT, int WMODE, bool SKEW, int THREADS>
 __device__ __forceinline__ void gn_small_body(const DvoSmallParams& p)
 {
@@ -2443,15 +2442,9 @@ __device__ __forceinline__ void gn_small_body(const DvoSmallParams& p)
                 stamp(2);
                 if (tid == 0) {
                     redo_sh = 0;
-                    // (out of line under the 168-register cap of the narrow workgroups; under the 128 of the 1024-thread workgroup the
-                    // function itself would spill, inside its call frame, more than the inlined step does: 347 -> 1131 us)
                     const double lam_known = (WMODE == 1 && !pred && p.st_one_pass != 0) ? lam_exact : -1.0;
-                    if constexpr (THREADS == DVO_SMALL_MAX_THREADS)
-                        gn_control(ctl, 0, pair, st, T_sh, &active_sh, &wpar_sh, rec_sh, &wsum[0][0], nullptr, (WMODE == 1) ? &redo_sh : nullptr,
-                                   p.lambda0, (WMODE == 1 && pred) ? 2 : 0, lam_known);
-                    else
-                        gn_control_small(&ctl, pair, &st, T_sh, &active_sh, &wpar_sh, rec_sh, &wsum[0][0], (WMODE == 1) ? &redo_sh : nullptr,
-                                         p.lambda0, (WMODE == 1 && pred) ? 2 : 0, lam_known);
+                    gn_control_small(&ctl, pair, &st, T_sh, &active_sh, &wpar_sh, rec_sh, &wsum[0][0], (WMODE == 1) ? &redo_sh : nullptr,
+                                     p.lambda0, (WMODE == 1 && pred) ? 2 : 0, lam_known);
                     if (WMODE == 1 && p.st_counts != nullptr && pred) {
                         atomicAdd(p.st_counts + (redo_sh ? 1 : 0), 1);
                         if (redo_sh == 2) atomicAdd(p.st_counts + 2, 1);
@@ -2474,12 +2467,14 @@ __device__ __forceinline__ void gn_small_body(const DvoSmallParams& p)
     }
 }
 
-// The three launched shapes.  The register budget is part of the shape: a 1024-thread workgroup is 4 waves per SIMD = 128 VGPRs;
-// the narrow workgroups are compiled for 3 waves per SIMD (168 VGPRs): beside one such wave a SIMD still holds three
-// 96-register waves of another stream's reduction.  (The budget comes in steps of 512 / waves: the next one, 256, lets the
-// control step run without spills and the isolated launch finish 11 % sooner, but costs the four-stream job 1 %.)
+// The three launched shapes, all compiled for 4 waves per SIMD (128 VGPRs: what a 1024-thread workgroup allows anyway).  The
+// record loops and reductions need ~100 registers; the one-lane float64 control step, which needs ~165, is a function
+// (gn_control_small) and spills inside its own frame.  For the narrow workgroups the budget is a choice, and a job-level one:
+// beside a 128-register wave of this kernel a SIMD holds FOUR 96-register waves of another stream's reduction, beside a
+// 168-register one three, and the reduction is saturated from four waves per SIMD up (168 -> 128: isolated launch unchanged,
+// four-stream job +1.5 %; 253 registers: isolated launch -11 %, job -1 %).
 #ifndef DVO_SMALL_MINW
-#define DVO_SMALL_MINW 3
+#define DVO_SMALL_MINW 4
 #endif
 template <int VARIANT, int WMODE, bool SKEW>
 __global__ __launch_bounds__(256, DVO_SMALL_MINW) void k_gn_small_256(const DvoSmallParams p)
