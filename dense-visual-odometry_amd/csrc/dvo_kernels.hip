@@ -2146,6 +2146,9 @@ __global__ __launch_bounds__(64) void k_solve(const DvoSolveParams p)
 {
     const int pair = blockIdx.x;
     if (p.active[pair] == 0) return;
+    // this wave is a serial chain on its stream's critical path, sharing its SIMD with four or five reduction waves of other
+    // streams: its instructions go first whenever they are ready (the SIMD arbitrates by priority, then age)
+    __builtin_amdgcn_s_setprio(3);
     __shared__ double rec[DVO_STRIDE];
     __shared__ double rec2[DVO_STRIDE];
     __shared__ double tmp[8][DVO_STRIDE];
@@ -2441,6 +2444,7 @@ __device__ __forceinline__ void gn_small_body(const DvoSmallParams& p)
                 __syncthreads();
                 stamp(2);
                 if (tid == 0) {
+                    __builtin_amdgcn_s_setprio(3);          // the one-lane control chain goes first on its SIMD (see k_solve)
                     redo_sh = 0;
                     const double lam_known = (WMODE == 1 && !pred && p.st_one_pass != 0) ? lam_exact : -1.0;
                     gn_control_small(&ctl, pair, &st, T_sh, &active_sh, &wpar_sh, rec_sh, &wsum[0][0], (WMODE == 1) ? &redo_sh : nullptr,
@@ -2450,6 +2454,7 @@ __device__ __forceinline__ void gn_small_body(const DvoSmallParams& p)
                         if (redo_sh == 2) atomicAdd(p.st_counts + 2, 1);
                         if (redo_sh && li == 0) atomicAdd(p.st_counts + 3, 1);
                     }
+                    __builtin_amdgcn_s_setprio(0);
                 }
                 __syncthreads();
                 stamp(3);
