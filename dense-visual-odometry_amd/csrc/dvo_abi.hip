@@ -148,6 +148,7 @@ struct dvo_ctx {
         int small_threads = 0;          // DVO_SMALL_THREADS: workgroup size of k_gn_small (0: chosen from the batch size)
         bool st_exact = false;          // DVO_ST_EXACT: the reference's Student-t always as its three passes (no moment form)
         bool st_small_exact = false;    // DVO_ST_SMALL_EXACT: ... at the persistent levels only (A/B of k_gn_small's one-pass iterations)
+        bool st_debug = false;          // DVO_ST_DEBUG (experiment builds): fallback decisions on stderr
         int exp_taps = 0;               // DVO_EXP_TAPS=1..4: dvo_normal_equations (V1, unweighted) runs an experimental tap
                                         // formulation of the reduction (dvo_exp_taps.inc; tools/exp_taps.py); never the solve path
     } knobs;
@@ -302,8 +303,13 @@ hipError_t launch_reduce_profiled(dvo_ctx* ctx, const DvoReduceParams& p, int le
         b = pool_event(ctx);
         if (a && b) (void)hipEventRecord(a, ctx->stream);
     }
+#ifdef DVO_EXPERIMENTS
     hipError_t e = exp_mode ? dvo_launch_reduce_exp(p, exp_mode, ctx->d_exp_gradh, ctx->d_exp_ipl, ctx->exp_plane_texels, ctx->stream)
                             : dvo_launch_reduce(p, variant, weight_mode, scale_pass, ctx->stream);
+#else
+    (void)exp_mode;
+    hipError_t e = dvo_launch_reduce(p, variant, weight_mode, scale_pass, ctx->stream);
+#endif
     if (ctx->profiling && a && b) {
         (void)hipEventRecord(b, ctx->stream);
         ctx->pending.push_back({a, b, level});
@@ -325,7 +331,7 @@ int fill_reduce_params(dvo_ctx* ctx, int level, int n_pairs, int w, int h, DvoRe
     p->T = ctx->d_T;
     p->wparam = ctx->d_wparam;
     p->active = nullptr;
-    p->finest = (level == 0) ? (ctx->profiling ? 2 : 1) : 0;
+    p->nt_records = (level == 0) ? 1 : 0;          // the finest level's records go around the caches (read once per launch)
     p->partials = ctx->d_partials;
     p->partials2 = nullptr;
     p->lambda0 = 0.04f;
@@ -498,29 +504,34 @@ int dvo_create(int device, int max_w, int max_h, int max_levels, int n_slots, in
     CREATE_TRY(hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
     CREATE_TRY(hipStreamSynchronize(ctx->stream));
     {
+        // product knobs (listed in include/dvo_hip.h, "Environment"): read ONCE here, never on a per-call path
         const char* e = getenv("DVO_GRAPH");
         ctx->graphs_enabled = !(e && e[0] == '0');
+        ctx->knobs.st_solve_phases = getenv("DVO_ST_SOLVE_PHASES") != nullptr;
+        ctx->knobs.no_rcache = getenv("DVO_NO_RCACHE") != nullptr;
+        ctx->knobs.ingest_unfused = getenv("DVO_INGEST_UNFUSED") != nullptr;
+        ctx->knobs.st_exact = getenv("DVO_ST_EXACT") != nullptr;
+        ctx->knobs.st_small_exact = getenv("DVO_ST_SMALL_EXACT") != nullptr;
+        e = getenv("DVO_SMALL_MAX_PIX");
+        if (e) ctx->knobs.small_max_pix = atoi(e);
+        e = getenv("DVO_SMALL_THREADS");
+        if (e && (atoi(e) == 256 || atoi(e) == 512 || atoi(e) == 1024)) ctx->knobs.small_threads = atoi(e);
+#ifdef DVO_EXPERIMENTS
+        // tuning / diagnostic knobs of experiment builds (make EXTRA=-DDVO_EXPERIMENTS): not in the product library
         e = getenv("DVO_XCD_REMAP");
         ctx->knobs.xcd_remap = (e && e[0] == '1') ? 1 : 0;
         e = getenv("DVO_MAX_GROUPS");
         if (e && atoi(e) > 0) ctx->knobs.max_groups = atoi(e);
         e = getenv("DVO_TARGET_BLOCKS");
         if (e && atoi(e) > 0) ctx->knobs.target_blocks = atoi(e);
-        ctx->knobs.st_solve_phases = getenv("DVO_ST_SOLVE_PHASES") != nullptr;
-        ctx->knobs.no_rcache = getenv("DVO_NO_RCACHE") != nullptr;
-        ctx->knobs.ingest_unfused = getenv("DVO_INGEST_UNFUSED") != nullptr;
-        ctx->knobs.st_exact = getenv("DVO_ST_EXACT") != nullptr;
-        ctx->knobs.st_small_exact = getenv("DVO_ST_SMALL_EXACT") != nullptr;
+        ctx->knobs.st_debug = getenv("DVO_ST_DEBUG") != nullptr;
         if (getenv("DVO_SMALL_STAMPS") != nullptr) {
             CREATE_TRY(hipMalloc((void**)&ctx->d_small_stamps, (size_t)max_pairs * 8 * sizeof(unsigned long long)));
             CREATE_TRY(hipMemset(ctx->d_small_stamps, 0, (size_t)max_pairs * 8 * sizeof(unsigned long long)));
         }
         e = getenv("DVO_EXP_TAPS");
         if (e) ctx->knobs.exp_taps = atoi(e);
-        e = getenv("DVO_SMALL_MAX_PIX");
-        if (e) ctx->knobs.small_max_pix = atoi(e);
-        e = getenv("DVO_SMALL_THREADS");
-        if (e && (atoi(e) == 256 || atoi(e) == 512 || atoi(e) == 1024)) ctx->knobs.small_threads = atoi(e);
+#endif
     }
 #undef CREATE_TRY
     *out = ctx;
@@ -989,6 +1000,7 @@ int dvo_normal_equations(dvo_ctx* ctx, int level, int n_pairs, const int* prev_s
     rc = fill_reduce_params(ctx, level, n_pairs, w, h, &p);
     if (rc) return rc;
     int exp_mode = 0;
+#ifdef DVO_EXPERIMENTS
     if (ctx->knobs.exp_taps && variant == DVO_VARIANT_V1 && weight_mode == 0 && p.cam.skew0) {
         // experimental tap formulations: side planes of the current frames, rebuilt on every call (test hook, not timed)
         exp_mode = ctx->knobs.exp_taps;
@@ -1002,6 +1014,7 @@ int dvo_normal_equations(dvo_ctx* ctx, int level, int n_pairs, const int* prev_s
         HIP_TRY(ctx, dvo_launch_exp_convert(ctx->d_slots, ctx->slot_stride, p.g, ctx->d_cur, n_pairs, ctx->d_exp_gradh, ctx->d_exp_ipl,
                                             ctx->exp_plane_texels, ctx->stream));
     }
+#endif
     HIP_TRY(ctx, launch_reduce_profiled(ctx, p, level, variant, weight_mode, 0, exp_mode));
     HIP_TRY(ctx, dvo_launch_sum_partials(ctx->d_partials, p.blocks_per_pair, n_pairs, ctx->d_out, ctx->stream));
     HIP_TRY(ctx, hipMemcpyAsync(ctx->hs.out, ctx->d_out, (size_t)n_pairs * DVO_STRIDE * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
@@ -1212,7 +1225,7 @@ static int record_solve(dvo_ctx* ctx, const SolveKey& k, const float* d_init)
         // instead of scale pass + cached scale pass + weighted pass, wherever the level is large enough for its bound to hold on
         // ordinary images (>= 320x240); a solve whose bound fails is repeated with the three-pass form by dvo_solve_batch_fetch.
         const bool moment_form = (weight_mode == DVO_WEIGHT_STUDENT_T) && !k.st_exact && !ctx->knobs.st_solve_phases &&
-                                 variant != DVO_VARIANT_V3 && ctx->d_partials2 != nullptr && p.g.npix >= 76800;
+                                 variant == DVO_VARIANT_V1 && ctx->d_partials2 != nullptr && p.g.npix >= 76800;
         HIP_TRY(ctx, dvo_launch_level_begin(ctx->d_state, ctx->d_active, ctx->d_wparam, n_pairs, weight_mode, lambda0, ctx->stream));
         for (int it = 0; it < k.level_iters[level]; ++it) {
             if (moment_form) {
@@ -1380,7 +1393,7 @@ int dvo_solve_batch_fetch(dvo_ctx* ctx, int n_pairs, float* T_out, double* xi_ou
     if (ctx->last_moment) HIP_TRY(ctx, hipMemcpyAsync(ctx->h_inexact, ctx->d_inexact, 8 * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     if (ctx->last_moment) { ctx->st_small_kept += ctx->h_inexact[4]; ctx->st_small_redone += ctx->h_inexact[5]; }
-    if (ctx->last_moment && getenv("DVO_ST_DEBUG") && ctx->h_inexact[5])
+    if (ctx->last_moment && ctx->knobs.st_debug && ctx->h_inexact[5])
         fprintf(stderr, "dvo: persistent levels: %d one-pass iterations kept, %d run again (%d for the IRLS shape / series, %d at the coarsest level)\n",
                 ctx->h_inexact[4], ctx->h_inexact[5], ctx->h_inexact[6], ctx->h_inexact[7]);
     if (ctx->last_moment && *ctx->h_inexact != 0) {
@@ -1388,7 +1401,7 @@ int dvo_solve_batch_fetch(dvo_ctx* ctx, int n_pairs, float* T_out, double* xi_ou
         // solve again with the reference's passes as written (slot ids and initial poses are still in their device buffers)
         ctx->last_moment = false;
         ctx->st_fallbacks += 1;
-        if (getenv("DVO_ST_DEBUG"))
+        if (ctx->knobs.st_debug)
             fprintf(stderr, "dvo: Student-t one-pass form rejected in %d iteration(s) (IRLS shape %d, moment bound %d, predicted bound %d): repeating with the three-pass form\n",
                     ctx->h_inexact[0], ctx->h_inexact[1], ctx->h_inexact[2], ctx->h_inexact[3]);
         SolveKey key = ctx->last_key;
@@ -1404,16 +1417,18 @@ int dvo_solve_batch_fetch(dvo_ctx* ctx, int n_pairs, float* T_out, double* xi_ou
     return DVO_OK;
 }
 
+#ifdef DVO_EXPERIMENTS
 int dvo_debug_small_stamps(dvo_ctx* ctx, int n_pairs, uint64_t* out, int reset)
 {
     if (!ctx || !out || n_pairs <= 0 || n_pairs > ctx->max_pairs) return DVO_ERR_INVALID_ARG;
-    if (!ctx->d_small_stamps) return fail(ctx, DVO_ERR_BAD_STATE, "dvo_debug_small_stamps: create the ctx with DVO_SMALL_STAMPS set");
+    if (!ctx->d_small_stamps) return fail(ctx, DVO_ERR_BAD_STATE, "dvo_debug_small_stamps: needs a library built with -DDVO_EXPERIMENTS and a ctx created under DVO_SMALL_STAMPS");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     HIP_TRY(ctx, hipMemcpy(out, ctx->d_small_stamps, (size_t)n_pairs * 8 * sizeof(uint64_t), hipMemcpyDeviceToHost));
     if (reset) HIP_TRY(ctx, hipMemset(ctx->d_small_stamps, 0, (size_t)ctx->max_pairs * 8 * sizeof(unsigned long long)));
     return DVO_OK;
 }
+#endif
 
 int dvo_student_t_fallbacks(const dvo_ctx* ctx, int64_t* count)
 {

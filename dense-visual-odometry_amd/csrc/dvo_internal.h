@@ -59,7 +59,7 @@ struct DvoReduceParams {
     float lambda0;              // weight mode 5 (Student-t, predicted lambda): 1 / initial_sigma^2 of the first scale pass
     int blocks_per_pair;
     int xcd_remap;              // 1: XCD-aware logical block order
-    int finest;                 // level == 0 (kernel-name tag only)
+    int nt_records;             // 1: the valid-point records are loaded non-temporally (level 0: read once per launch)
     int groups_per_block;       // each workgroup reduces groups_per_block * DVO_PX_PER_BLOCK list records of one pair
     int n_pairs;
     const int* list_count;      // [n_slots][DVO_LIST_LEVELS] number of records in each slot's list
@@ -202,8 +202,10 @@ hipError_t dvo_launch_gn_small(const DvoSmallParams& p, int variant, int threads
 hipError_t dvo_launch_debug_divide(const float* a, const float* b, float* out, float* ref, int n, hipStream_t s);
 hipError_t dvo_launch_finish(const DvoPairState* st, int n_pairs, double* xi_out, int* iters_out, double* err_out,
                              hipStream_t s);
+#ifdef DVO_EXPERIMENTS
 // experimental tap formulations of the level-0 reduction (dvo_exp_taps.inc; DVO_EXP_TAPS knob, tools/exp_taps.py)
 hipError_t dvo_launch_exp_convert(const uint8_t* slots, size_t slot_stride, const DvoLevelGeom& g, const int* slot_ids, int n_slots,
                                   uint32_t* gradh, uint8_t* ipl, size_t plane_texels, hipStream_t s);
 hipError_t dvo_launch_reduce_exp(const DvoReduceParams& p, int mode, const uint32_t* gradh, const uint8_t* ipl, size_t plane_texels,
                                  hipStream_t s);
+#endif

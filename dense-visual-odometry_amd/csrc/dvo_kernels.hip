@@ -697,11 +697,8 @@ hipError_t dvo_launch_batch_ingest(const DvoBatchIngestParams& p, hipStream_t s)
 // the per-pixel pipeline shared by K3 and K5
 // ================================================================================================
 // Valid-point records are read once per launch: a non-temporal load (`nt`) keeps them from displacing the texel lines and the
-// coarser levels' data in the L2 / Infinity Cache.  DVO_NT_RECORDS(TAG) says for which kernels (TAG != 0: level 0).
-#ifndef DVO_NT_MODE
-#define DVO_NT_MODE 1               // 0: never, 1: level 0 (kernel tags 1, 2), 2: every level
-#endif
-#define DVO_NT_RECORDS(TAG) (DVO_NT_MODE == 2 || (DVO_NT_MODE == 1 && (TAG) != 0))
+// coarser levels' data in the L2 / Infinity Cache.  Which launches do so is a launch parameter (DvoReduceParams::nt_records:
+// level 0), tested once per record group by a wave-uniform branch around the group's four loads.
 template <bool NT>
 __device__ __forceinline__ uint2 dvo_rec_load(const uint2* p)
 {
@@ -1038,9 +1035,7 @@ __device__ __forceinline__ double student_t_lambda(const DvoReduceParams& p, int
     return lam_sh;
 }
 
-// TAG only names the instantiation so that rocprofv3 --stats lists these dispatches on their own line; codegen is
-// identical.  0: coarser levels, 1: level 0, 2: level 0 while the ctx is in profiling mode (bench.py's roofline leg).
-template <int VARIANT, int WMODE, bool SCALE_PASS, int TAG, bool SKEW>
+template <int VARIANT, int WMODE, bool SCALE_PASS, bool SKEW>
 __global__ __launch_bounds__(DVO_BLOCK, (VARIANT == 2) ? 2 : DVO_REDUCE_WAVES_PER_SIMD) void k_reduce(const DvoReduceParams p)
 {
     constexpr int NACC = SCALE_PASS ? 2 : (WMODE == 5 ? DVO_STRIDE : DVO_NACC);       // scale pass: sum of the weighted r^2, number of residuals
@@ -1118,9 +1113,15 @@ __global__ __launch_bounds__(DVO_BLOCK, (VARIANT == 2) ? 2 : DVO_REDUCE_WAVES_PE
     uint2 rn[DVO_PX_PER_THREAD];
 #pragma unroll
     for (int j = 0; j < DVO_PX_PER_THREAD; ++j) rn[j] = make_uint2(0u, 0u);
+    const bool nt_records = p.nt_records != 0;                            // launch-uniform
     if (g_lo < g_hi && rec0 < count) {
+        if (nt_records) {
 #pragma unroll
-        for (int j = 0; j < DVO_PX_PER_THREAD; ++j) rn[j] = dvo_rec_load<DVO_NT_RECORDS(TAG)>(reinterpret_cast<const uint2*>(list + rec0 + j * 64 + lane_));
+            for (int j = 0; j < DVO_PX_PER_THREAD; ++j) rn[j] = dvo_rec_load<true>(reinterpret_cast<const uint2*>(list + rec0 + j * 64 + lane_));
+        } else {
+#pragma unroll
+            for (int j = 0; j < DVO_PX_PER_THREAD; ++j) rn[j] = dvo_rec_load<false>(reinterpret_cast<const uint2*>(list + rec0 + j * 64 + lane_));
+        }
     }
     for (int grp = g_lo; grp < g_hi; ++grp) {
         const int seg = grp * DVO_PX_PER_BLOCK + wave_off;
@@ -1131,8 +1132,13 @@ __global__ __launch_bounds__(DVO_BLOCK, (VARIANT == 2) ? 2 : DVO_REDUCE_WAVES_PE
         {
             const int segn = seg + DVO_PX_PER_BLOCK;
             if (grp + 1 < g_hi && segn < count) {                         // (reads past `count` stay inside DVO_LIST_SLACK)
+                if (nt_records) {
 #pragma unroll
-                for (int j = 0; j < DVO_PX_PER_THREAD; ++j) rn[j] = dvo_rec_load<DVO_NT_RECORDS(TAG)>(reinterpret_cast<const uint2*>(list + segn + j * 64 + lane_));
+                    for (int j = 0; j < DVO_PX_PER_THREAD; ++j) rn[j] = dvo_rec_load<true>(reinterpret_cast<const uint2*>(list + segn + j * 64 + lane_));
+                } else {
+#pragma unroll
+                    for (int j = 0; j < DVO_PX_PER_THREAD; ++j) rn[j] = dvo_rec_load<false>(reinterpret_cast<const uint2*>(list + segn + j * 64 + lane_));
+                }
             }
         }
         // phase A for all pixels of the lane, then all tap loads back to back (memory-level parallelism: the
@@ -1318,49 +1324,49 @@ hipError_t dvo_launch_scale_cached(const DvoReduceParams& p, hipStream_t s)
     return hipGetLastError();
 }
 
-template <int VARIANT, int TAG, bool SKEW>
+// Which instantiations exist (the library's kernel inventory is deliberate, see include/dvo_hip.h "build"):
+//   * the GENERAL kernels (SKEW = true: every term of the reference's matrix expressions, exact for any camera, and for a
+//     camera without skew bit-identical to the fast ones since x + (+-0) == x) for every variant and weighting;
+//   * FAST kernels (SKEW = false: the zero-skew terms dropped, 4 instructions per point) for the paths that are measured:
+//     every weighting of the reference default V1 (incl. its one-pass Student-t forms 4 / 5) and the unweighted V2 / GN;
+//   * the one-pass Student-t forms (weight modes 4 / 5) for V1 only: the other variants run the passes as written.
+template <int VARIANT, bool SKEW>
 static hipError_t launch_reduce_v(const DvoReduceParams& p, int weight_mode, int scale_pass, hipStream_t s)
 {
     dim3 grid((unsigned)(p.n_pairs * p.blocks_per_pair)), block(DVO_BLOCK);
     if (scale_pass) {
-        hipLaunchKernelGGL((k_reduce<VARIANT, 1, true, TAG, SKEW>), grid, block, 0, s, p);
+        hipLaunchKernelGGL((k_reduce<VARIANT, 1, true, SKEW>), grid, block, 0, s, p);
     } else if (weight_mode == 0) {
-        hipLaunchKernelGGL((k_reduce<VARIANT, 0, false, TAG, SKEW>), grid, block, 0, s, p);
+        hipLaunchKernelGGL((k_reduce<VARIANT, 0, false, SKEW>), grid, block, 0, s, p);
     } else if (weight_mode == 1 || weight_mode == 3) {          // both Student-t forms weight with 6 / (5 + r^2 lambda)
-        hipLaunchKernelGGL((k_reduce<VARIANT, 1, false, TAG, SKEW>), grid, block, 0, s, p);
+        hipLaunchKernelGGL((k_reduce<VARIANT, 1, false, SKEW>), grid, block, 0, s, p);
     } else if (weight_mode == 4) {                              // internal: the reference's Student-t in one pass (moment form)
-        if constexpr (VARIANT == 2) return hipErrorInvalidValue;
-        else hipLaunchKernelGGL((k_reduce<VARIANT, 4, false, TAG, SKEW>), grid, block, 0, s, p);
+        if constexpr (VARIANT != 0) return hipErrorInvalidValue;
+        else hipLaunchKernelGGL((k_reduce<VARIANT, 4, false, SKEW>), grid, block, 0, s, p);
     } else if (weight_mode == 5) {                              // internal: ... weighted with the predicted lambda
-        if constexpr (VARIANT == 2) return hipErrorInvalidValue;
-        else hipLaunchKernelGGL((k_reduce<VARIANT, 5, false, TAG, SKEW>), grid, block, 0, s, p);
+        if constexpr (VARIANT != 0) return hipErrorInvalidValue;
+        else hipLaunchKernelGGL((k_reduce<VARIANT, 5, false, SKEW>), grid, block, 0, s, p);
     } else {
-        hipLaunchKernelGGL((k_reduce<VARIANT, 2, false, TAG, SKEW>), grid, block, 0, s, p);
+        hipLaunchKernelGGL((k_reduce<VARIANT, 2, false, SKEW>), grid, block, 0, s, p);
     }
     return hipGetLastError();
 }
 
 hipError_t dvo_launch_reduce(const DvoReduceParams& p, int variant, int weight_mode, int scale_pass, hipStream_t s)
 {
-    if (variant == 2) return launch_reduce_v<2, 0, false>(p, weight_mode, scale_pass, s);      // V3: no per-level kernel tags
-    if (variant == 3) {                         // GN: no per-level kernel tags either
-        if (!p.cam.skew0) return launch_reduce_v<3, 0, true>(p, weight_mode, scale_pass, s);
-        return launch_reduce_v<3, 0, false>(p, weight_mode, scale_pass, s);
+    if (variant == 2) return launch_reduce_v<2, true>(p, weight_mode, scale_pass, s);          // V3: float64 geometry of its own (SKEW unused)
+    const bool fast = p.cam.skew0 != 0;
+    if (variant == 0) return fast ? launch_reduce_v<0, false>(p, weight_mode, scale_pass, s) : launch_reduce_v<0, true>(p, weight_mode, scale_pass, s);
+    const bool plain = (weight_mode == 0) && !scale_pass;
+    if (variant == 1) {
+        if (fast && plain) { hipLaunchKernelGGL((k_reduce<1, 0, false, false>), dim3((unsigned)(p.n_pairs * p.blocks_per_pair)), dim3(DVO_BLOCK), 0, s, p); return hipGetLastError(); }
+        return launch_reduce_v<1, true>(p, weight_mode, scale_pass, s);
     }
-    if (!p.cam.skew0) {                         // cameras with a skew term: general expressions, no per-level tags
-        if (variant == 0) return launch_reduce_v<0, 0, true>(p, weight_mode, scale_pass, s);
-        return launch_reduce_v<1, 0, true>(p, weight_mode, scale_pass, s);
+    if (variant == 3) {
+        if (fast && plain) { hipLaunchKernelGGL((k_reduce<3, 0, false, false>), dim3((unsigned)(p.n_pairs * p.blocks_per_pair)), dim3(DVO_BLOCK), 0, s, p); return hipGetLastError(); }
+        return launch_reduce_v<3, true>(p, weight_mode, scale_pass, s);
     }
-    if (p.finest == 2) {
-        if (variant == 0) return launch_reduce_v<0, 2, false>(p, weight_mode, scale_pass, s);
-        return launch_reduce_v<1, 2, false>(p, weight_mode, scale_pass, s);
-    }
-    if (p.finest == 1) {
-        if (variant == 0) return launch_reduce_v<0, 1, false>(p, weight_mode, scale_pass, s);
-        return launch_reduce_v<1, 1, false>(p, weight_mode, scale_pass, s);
-    }
-    if (variant == 0) return launch_reduce_v<0, 0, false>(p, weight_mode, scale_pass, s);
-    return launch_reduce_v<1, 0, false>(p, weight_mode, scale_pass, s);
+    return hipErrorInvalidValue;
 }
 
 // ================================================================================================
@@ -2211,13 +2217,15 @@ __device__ __forceinline__ void wave_reduce_terms(const float* acc, float* wbuf 
     if (lane >= NT && lane < DVO_STRIDE) out[lane] = 0.0;
 }
 
-// THREADS = the launched workgroup size (256 / 512 / 1024): sizes the LDS arrays and the loop strides for that shape.
-template <int VARIANT, int WMODE, bool SKEW, int THREADS>
+// ONE kernel for the three launched workgroup sizes (256 / 512 / 1024 threads; blockDim.x is read at run time): all of them are
+// compiled for 4 waves per SIMD (128 VGPRs: what a 1024-thread workgroup allows anyway), so the code is the same and only the
+// loop strides and the number of wave totals differ.  The per-wave transpose buffers (the one LDS array whose size depends on
+// the shape: 2080 bytes per wave) are dynamic shared memory sized by dvo_launch_gn_small; the rest is sized for 16 waves (4.7 KB).
+template <int VARIANT, int WMODE, bool SKEW>
 __device__ __forceinline__ void gn_small_body(const DvoSmallParams& p)
 {
     static_assert(VARIANT == 0 || VARIANT == 1 || VARIANT == 3, "V3 keeps the per-iteration launches");
-    static_assert(THREADS == 256 || THREADS == 512 || THREADS == DVO_SMALL_MAX_THREADS, "workgroup sizes of dvo_launch_gn_small");
-    constexpr int NWAVES = THREADS / 64;
+    constexpr int NWAVES = DVO_SMALL_MAX_WAVES;
     __shared__ DvoPairState st;
     __shared__ float T_sh[12];
     __shared__ int active_sh;
@@ -2225,13 +2233,14 @@ __device__ __forceinline__ void gn_small_body(const DvoSmallParams& p)
     __shared__ DvoControlParams ctl;
     __shared__ double wpar_sh;
     __shared__ double rec_sh[DVO_STRIDE];
-    __shared__ double wsum[(NWAVES * DVO_STRIDE >= 72) ? NWAVES : 3][DVO_STRIDE];      // (also the 72-double workspace of solve6_pinv)
+    __shared__ double wsum[NWAVES][DVO_STRIDE];      // (also the 72-double workspace of solve6_pinv)
     __shared__ double scal[2][NWAVES];
     __shared__ double scnt_sh[2][NWAVES];
-    __shared__ float wbuf[NWAVES][8 * 65];
+    extern __shared__ float wbuf_dyn[];              // [waves launched][8 * 65]
     const int pair = blockIdx.x, tid = threadIdx.x;
     const int lane_ = tid & 63, wave_ = tid >> 6;
-    constexpr int nwaves = NWAVES;
+    const int nwaves = (int)(blockDim.x >> 6);
+    float* wbuf_mine = wbuf_dyn + wave_ * (8 * 65);
     if (tid == 0) {
         st = p.state[pair]; active_sh = 1; wpar_sh = p.wparam[pair];
         ctl.tolerance = p.tolerance; ctl.weight_param = p.weight_param; ctl.inv_sigma = p.inv_sigma;
@@ -2243,10 +2252,14 @@ __device__ __forceinline__ void gn_small_body(const DvoSmallParams& p)
     const int prev_id = p.prev_slot[pair];
     const uint8_t* prev = p.slots + (size_t)prev_id * p.slot_stride;
     const uint8_t* curs = p.slots + (size_t)p.cur_slot[pair] * p.slot_stride;
-    constexpr int gstride = THREADS * DVO_PX_PER_THREAD;                          // records per group of the workgroup
+    const int gstride = (int)blockDim.x * DVO_PX_PER_THREAD;                      // records per group of the workgroup
     const int rec0 = wave_ * (64 * DVO_PX_PER_THREAD);
-    // diagnostic stamps (p.stamps != null only under DVO_SMALL_STAMPS; workgroup-uniform branches around s_memtime otherwise)
+    // diagnostic stamps (experiment builds only, -DDVO_EXPERIMENTS + DVO_SMALL_STAMPS: workgroup-uniform branches around s_memtime)
+#ifdef DVO_EXPERIMENTS
     const bool stamping = p.stamps != nullptr;
+#else
+    constexpr bool stamping = false;
+#endif
     unsigned long long tk[6] = {0, 0, 0, 0, 0, 0}, t_last = 0, t_begin = 0;
     auto stamp = [&](int k) {
         if (stamping) {
@@ -2433,7 +2446,7 @@ __device__ __forceinline__ void gn_small_body(const DvoSmallParams& p)
                 }
                 if constexpr (WMODE == 0) acc[DVO_NACC - 1] = acc[DVO_NACC - 3];
                 stamp(0);
-                wave_reduce_terms<NT>(acc, wbuf[wave_], wsum[wave_]);
+                wave_reduce_terms<NT>(acc, wbuf_mine, wsum[wave_]);
                 __syncthreads();
                 stamp(1);
                 if (tid < DVO_STRIDE) {
@@ -2472,53 +2485,47 @@ __device__ __forceinline__ void gn_small_body(const DvoSmallParams& p)
     }
 }
 
-// The three launched shapes, all compiled for 4 waves per SIMD (128 VGPRs: what a 1024-thread workgroup allows anyway).  The
-// record loops and reductions need ~100 registers; the one-lane float64 control step, which needs ~165, is a function
-// (gn_control_small) and spills inside its own frame.  For the narrow workgroups the budget is a choice, and a job-level one:
-// beside a 128-register wave of this kernel a SIMD holds FOUR 96-register waves of another stream's reduction, beside a
-// 168-register one three, and the reduction is saturated from four waves per SIMD up (168 -> 128: isolated launch unchanged,
-// four-stream job +1.5 %; 253 registers: isolated launch -11 %, job -1 %).
-#ifndef DVO_SMALL_MINW
-#define DVO_SMALL_MINW 4
-#endif
+// Compiled for 4 waves per SIMD (128 VGPRs).  The record loops and reductions need ~100 registers; the one-lane float64 control
+// step, which needs ~165, is a function (gn_control_small) and spills inside its own frame.  For the narrow workgroups the budget
+// is a choice, and a job-level one: beside a 128-register wave of this kernel a SIMD holds FOUR 96-register waves of another
+// stream's reduction, beside a 168-register one three, and the reduction is saturated from four waves per SIMD up (168 -> 128:
+// isolated launch unchanged, four-stream job +1.5 %; 253 registers: isolated launch -11 %, job -1 %).
 template <int VARIANT, int WMODE, bool SKEW>
-__global__ __launch_bounds__(256, DVO_SMALL_MINW) void k_gn_small_256(const DvoSmallParams p)
+__global__ __launch_bounds__(DVO_SMALL_MAX_THREADS) void k_gn_small(const DvoSmallParams p)
 {
-    gn_small_body<VARIANT, WMODE, SKEW, 256>(p);
-}
-template <int VARIANT, int WMODE, bool SKEW>
-__global__ __launch_bounds__(512, DVO_SMALL_MINW) void k_gn_small_512(const DvoSmallParams p)
-{
-    gn_small_body<VARIANT, WMODE, SKEW, 512>(p);
-}
-template <int VARIANT, int WMODE, bool SKEW>
-__global__ __launch_bounds__(DVO_SMALL_MAX_THREADS) void k_gn_small_1024(const DvoSmallParams p)
-{
-    gn_small_body<VARIANT, WMODE, SKEW, DVO_SMALL_MAX_THREADS>(p);
+    gn_small_body<VARIANT, WMODE, SKEW>(p);
 }
 
+// Instantiations: the general kernels (SKEW = true) for every variant and weighting, fast ones (SKEW = false) for every
+// weighting of the reference default V1 and for the unweighted V2 / GN (as dvo_launch_reduce).
 hipError_t dvo_launch_gn_small(const DvoSmallParams& p, int variant, int threads, hipStream_t s)
 {
-    const dim3 grid((unsigned)p.n_pairs), block((unsigned)threads);
-    const bool skew = !p.cam[0].skew0;
-#define DVO_SMALL_LAUNCH(V, W, S)                                                                            \
-    do {                                                                                                     \
-        if (threads == 256) hipLaunchKernelGGL((k_gn_small_256<V, W, S>), grid, block, 0, s, p);            \
-        else if (threads == 512) hipLaunchKernelGGL((k_gn_small_512<V, W, S>), grid, block, 0, s, p);       \
-        else hipLaunchKernelGGL((k_gn_small_1024<V, W, S>), grid, block, 0, s, p);                          \
-    } while (0)
-#define DVO_SMALL_W(V, S)                                                     \
-    do {                                                                      \
-        if (p.weight_mode == 0) DVO_SMALL_LAUNCH(V, 0, S);                    \
-        else if (p.weight_mode == 1 || p.weight_mode == 3) DVO_SMALL_LAUNCH(V, 1, S);   \
-        else DVO_SMALL_LAUNCH(V, 2, S);                                       \
-    } while (0)
     if (threads != 256 && threads != 512 && threads != DVO_SMALL_MAX_THREADS) return hipErrorInvalidValue;
-    if (variant == 0) { if (skew) DVO_SMALL_W(0, true); else DVO_SMALL_W(0, false); }
-    else if (variant == 1) { if (skew) DVO_SMALL_W(1, true); else DVO_SMALL_W(1, false); }
-    else if (variant == 3) { if (skew) DVO_SMALL_W(3, true); else DVO_SMALL_W(3, false); }
-    else return hipErrorInvalidValue;
-#undef DVO_SMALL_W
+    const dim3 grid((unsigned)p.n_pairs), block((unsigned)threads);
+    const size_t lds = (size_t)(threads / 64) * 8 * 65 * sizeof(float);
+    const bool fast = p.cam[0].skew0 != 0;
+    const int wm = (p.weight_mode == 0) ? 0 : (p.weight_mode == 1 || p.weight_mode == 3) ? 1 : 2;
+#define DVO_SMALL_LAUNCH(V, W, S) hipLaunchKernelGGL((k_gn_small<V, W, S>), grid, block, lds, s, p)
+#define DVO_SMALL_GENERAL(V)                                   \
+    do {                                                       \
+        if (wm == 0) DVO_SMALL_LAUNCH(V, 0, true);             \
+        else if (wm == 1) DVO_SMALL_LAUNCH(V, 1, true);        \
+        else DVO_SMALL_LAUNCH(V, 2, true);                     \
+    } while (0)
+    if (variant == 0) {
+        if (fast) {
+            if (wm == 0) DVO_SMALL_LAUNCH(0, 0, false);
+            else if (wm == 1) DVO_SMALL_LAUNCH(0, 1, false);
+            else DVO_SMALL_LAUNCH(0, 2, false);
+        } else DVO_SMALL_GENERAL(0);
+    } else if (variant == 1) {
+        if (fast && wm == 0) DVO_SMALL_LAUNCH(1, 0, false);
+        else DVO_SMALL_GENERAL(1);
+    } else if (variant == 3) {
+        if (fast && wm == 0) DVO_SMALL_LAUNCH(3, 0, false);
+        else DVO_SMALL_GENERAL(3);
+    } else return hipErrorInvalidValue;
+#undef DVO_SMALL_GENERAL
 #undef DVO_SMALL_LAUNCH
     return hipGetLastError();
 }
@@ -2541,4 +2548,7 @@ hipError_t dvo_launch_finish(const DvoPairState* st, int n_pairs, double* xi_out
     return hipGetLastError();
 }
 
+#ifdef DVO_EXPERIMENTS
+// rejected formulations of the tap fetch (round 3), kept for A/B builds only: `make EXTRA=-DDVO_EXPERIMENTS OUT=...`
 #include "dvo_exp_taps.inc"
+#endif

@@ -82,12 +82,17 @@ SIGNATURES = {
     "dvo_trace_enable": (C.c_int, [_ctx, C.c_int]),
     "dvo_student_t_fallbacks": (C.c_int, [_ctx, _c_i64_p]),
     "dvo_student_t_small_level_counts": (C.c_int, [_ctx, _c_i64_p, _c_i64_p]),
-    "dvo_debug_small_stamps": (C.c_int, [_ctx, C.c_int, C.c_void_p, C.c_int]),
     "dvo_trace_read": (C.c_int, [_ctx, C.c_int, C.c_void_p]),
     "dvo_profile_enable": (C.c_int, [_ctx, C.c_int]),
     "dvo_profile_read": (C.c_int, [_ctx, _c_i64_p, _c_double_p, C.c_int]),
     "dvo_timer_start": (C.c_int, [_ctx]),
     "dvo_timer_stop": (C.c_int, [_ctx, _c_float_p]),
+}
+
+
+# entry points of experiment builds only (-DDVO_EXPERIMENTS, include/dvo_hip.h): bound when the loaded library has them
+EXPERIMENT_SIGNATURES = {
+    "dvo_debug_small_stamps": (C.c_int, [_ctx, C.c_int, C.c_void_p, C.c_int]),
 }
 
 
@@ -121,6 +126,11 @@ def load_library() -> C.CDLL:
         fn = getattr(lib, name)          # AttributeError if the .so does not export a declared symbol
         fn.restype = res
         fn.argtypes = args
+    for name, (res, args) in EXPERIMENT_SIGNATURES.items():
+        fn = getattr(lib, name, None)
+        if fn is not None:
+            fn.restype = res
+            fn.argtypes = args
     return lib
 
 
@@ -448,7 +458,10 @@ class HipContext:
         return int(kept.value), int(redone.value)
 
     def small_stamps(self, n_pairs: int, reset: bool = True) -> np.ndarray:
-        """(n_pairs, 8) uint64 phase clocks of the persistent small-level kernel (ctx created under DVO_SMALL_STAMPS)."""
+        """(n_pairs, 8) uint64 phase clocks of the persistent small-level kernel (experiment build of the library, -DDVO_EXPERIMENTS,
+        and a ctx created under DVO_SMALL_STAMPS)."""
+        if not hasattr(self._lib, "dvo_debug_small_stamps"):
+            raise DVOHipError(-4, "dvo_debug_small_stamps: the loaded library is not an experiment build (-DDVO_EXPERIMENTS)")
         out = np.zeros((n_pairs, 8), dtype=np.uint64)
         self._check(self._lib.dvo_debug_small_stamps(self._h, n_pairs, _ptr(out), int(bool(reset))))
         return out

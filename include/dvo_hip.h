@@ -263,13 +263,20 @@ int dvo_profile_enable(dvo_ctx* ctx, int on);
 /* Sums since the last reset: per level, number of reduction launches, their total device time (ms)
  * and total pixels / depth-valid pixels... read with n = DVO_MAX_LEVELS entries each. Blocks (syncs). */
 int dvo_profile_read(dvo_ctx* ctx, int64_t* launches, double* ms, int reset);
-/* Diagnostic (ctx created with the environment variable DVO_SMALL_STAMPS set): shader-clock ticks thread 0 of each pair's
- * workgroup of the persistent small-level kernel spent in {record loops, wave reduction, cross-wave sum, control step,
- * Student-t scale passes, whole kernel, -, -}, summed since the last reset: out[n_pairs][8]. */
-int dvo_debug_small_stamps(dvo_ctx* ctx, int n_pairs, uint64_t* out, int reset);
 /* Event-pair stopwatch on the ctx stream. */
 int dvo_timer_start(dvo_ctx* ctx);
 int dvo_timer_stop(dvo_ctx* ctx, float* ms);
+
+/* ---- experiment builds only ---------------------------------------------------------------------
+ * `make EXTRA=-DDVO_EXPERIMENTS OUT=<elsewhere>` adds what the A/B scripts under tools/ use and the product library does not
+ * contain: the rejected tap formulations of round 3 (csrc/dvo_exp_taps.inc, DVO_EXP_TAPS), the phase clocks of the persistent
+ * kernel (DVO_SMALL_STAMPS), the launch-shape knobs DVO_XCD_REMAP / DVO_MAX_GROUPS / DVO_TARGET_BLOCKS and DVO_ST_DEBUG. */
+#ifdef DVO_EXPERIMENTS
+/* ctx created with DVO_SMALL_STAMPS set: shader-clock ticks thread 0 of each pair's workgroup of the persistent small-level
+ * kernel spent in {record loops, wave reduction, cross-wave sum, control step, Student-t scale passes, whole kernel, -, -},
+ * summed since the last reset: out[n_pairs][8]. */
+int dvo_debug_small_stamps(dvo_ctx* ctx, int n_pairs, uint64_t* out, int reset);
+#endif
 
 #ifdef __cplusplus
 }

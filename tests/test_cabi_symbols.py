@@ -13,6 +13,7 @@ ROOT = Path(__file__).resolve().parents[1]
 def _declared_functions():
     text = (ROOT / "include" / "dvo_hip.h").read_text()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    text = re.sub(r"#ifdef DVO_EXPERIMENTS.*?#endif", "", text, flags=re.S)      # experiment builds only: not in the product library
     return sorted(set(re.findall(r"\b(dvo_[a-z0-9_]+)\s*\(", text)))
 
 

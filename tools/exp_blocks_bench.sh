@@ -1,4 +1,6 @@
 #!/bin/bash
+# needs the experiment build of the library: make -C dense-visual-odometry_amd/csrc experiments
+export DVO_HIP_LIB=${DVO_HIP_LIB:-$PWD/ab_libs/libdvo_hip_exp.so}
 # Workgroups per launch of the reduction (DVO_TARGET_BLOCKS / DVO_MAX_GROUPS), measured on the whole default job (4 streams).
 for cfg in "default default" "1024 20" "1024 38" "1024 75" "1024 150" "512 75"; do
   set -- $cfg

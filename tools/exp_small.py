@@ -9,6 +9,9 @@ ROOT = Path(__file__).resolve().parents[1]
 sys.path.insert(0, str(ROOT / "dense-visual-odometry_amd"))
 import numpy as np
 
+# needs the experiment build of the library: make -C dense-visual-odometry_amd/csrc experiments
+os.environ.setdefault("DVO_HIP_LIB", str(ROOT / "ab_libs" / "libdvo_hip_exp.so"))
+
 ap = argparse.ArgumentParser()
 ap.add_argument("--pairs", type=int, default=256)
 ap.add_argument("--weighting", default="none")

@@ -1,4 +1,6 @@
 #!/bin/bash
+# needs the experiment build of the library: make -C dense-visual-odometry_amd/csrc experiments
+export DVO_HIP_LIB=${DVO_HIP_LIB:-$PWD/ab_libs/libdvo_hip_exp.so}
 # PMC passes over the tap formulations of the level-0 reduction (tools/exp_taps.py: the product kernel and k_reduce_x<1..4> in one
 # process, so every pass counts all of them under the same conditions).  Each pass is its own run, counters only.
 #   tools/pmc_exp_taps.sh            -> gpurun_out/pmc_exp_taps.txt (per-dispatch averages of the level-0 launches of each kernel)
