@@ -10,6 +10,7 @@
 #include <cstring>
 #include <new>
 #include <vector>
+#include <climits>
 
 static_assert(DVO_LIST_LEVELS == DVO_MAX_LEVELS, "the list-count table has one column per pyramid level");
 static_assert(DVO_STRIDE == DVO_NE_STRIDE, "normal-equation record stride of the boundary");
@@ -22,6 +23,7 @@ struct SlotInfo {
     int w = 0, h = 0, levels = 0;
     bool ready = false;
     bool lists = false;     // valid-point lists built (needs the camera's depth_scale at upload time)
+    uint64_t epoch = 0;     // bumped by every upload into the slot (the Student-t fallback checks its frames are still the enqueued ones)
 };
 
 struct HostStage {          // pinned staging for the small per-call arrays
@@ -39,7 +41,11 @@ struct HostStage {          // pinned staging for the small per-call arrays
 
 struct SolveKey {
     int n_pairs, w, h, levels, max_iterations, max_increased, variant, weight_mode, has_init, trace_cap, has_last;
-    int st_exact;                       // Student-t of the reference: 1 = the three-pass form at every level (no moment form)
+    int st_exact;                       // Student-t of the reference: 0 = one-pass forms where they apply; 1 = the passes as written at the
+                                        // per-iteration levels (two scale passes + the weighted pass, no one-pass form anywhere); 2 = EVERY
+                                        // level in the persistent kernel, i.e. the reference's IRLS loop itself (the fallback for pairs
+                                        // whose loop does not take exactly two passes)
+    int trace_rows;                     // 1: trace rows through d_trace_row (re-solve of a compacted subset)
     double tolerance, weight_param, inv_sigma;
     const void* trace;
     const void* stream;
@@ -92,12 +98,23 @@ struct dvo_ctx {
     double* d_partials2 = nullptr;       // Student-t moment form: the r^2-weighted partial sums (same shape as d_partials)
     int* d_inexact = nullptr;            // ... iterations whose expansion bound was not met (device counter) and its page-locked copy
     int* h_inexact = nullptr;
-    bool last_moment = false;            // the solve enqueued last used the moment form (dvo_solve_batch_fetch may have to repeat it)
+    int* d_pair_flags = nullptr;         // Student-t of the reference: per pair, |= 1 one-pass bound not met, |= 2 IRLS not of the two-pass shape
+    int* h_pair_flags = nullptr;         // (page-locked copy)
+    int* d_trace_row = nullptr;          // trace row of each pair of a compacted re-solve
+    uint64_t upload_epoch = 0;
+    bool last_moment = false;            // the solve enqueued last is a Student-t solve of the reference (its per-pair flags and counters are read at fetch)
     SolveKey last_key;
     bool last_has_init = false;
-    int64_t st_fallbacks = 0;            // solves repeated with the three-pass form
-    int64_t st_small_kept = 0;           // k_gn_small: one-pass iterations kept / run again as written (over every fetched solve)
-    int64_t st_small_redone = 0;
+    // what the last Student-t solve was enqueued with: dvo_solve_batch_fetch re-stages the flagged pairs of it (host copies, so that
+    // T_init / the prior may change between enqueue and fetch; the frames themselves must not: epochs)
+    struct LastSolve {
+        std::vector<int> prev, cur;
+        std::vector<uint64_t> ep_prev, ep_cur;
+        std::vector<float> Tinit;
+        std::vector<double> prior;
+    } last;
+    int64_t st_fallbacks = 0;            // fetched solves in which at least one pair had to be solved again
+    int64_t st_fallback_pairs = 0;       // ... and how many pairs that were
     unsigned long long* d_small_stamps = nullptr;   // DVO_SMALL_STAMPS: [max_pairs][8] phase clocks of k_gn_small (diagnostic)
     float* d_rcache = nullptr;           // Student-t device solve: residuals kept between the scale passes [max_pairs][max_w*max_h]
     uint32_t* d_exp_gradh = nullptr;     // DVO_EXP_TAPS side planes [n_slots][exp_plane_texels]: {f16 gx, f16 gy} / intensity
@@ -147,8 +164,8 @@ struct dvo_ctx {
                                         // kernel k_gn_small (0: every level takes the per-iteration launches)
         int small_threads = 0;          // DVO_SMALL_THREADS: workgroup size of k_gn_small (0: chosen from the batch size)
         bool st_exact = false;          // DVO_ST_EXACT: the reference's Student-t always as its three passes (no moment form)
-        bool st_small_exact = false;    // DVO_ST_SMALL_EXACT: ... at the persistent levels only (A/B of k_gn_small's one-pass iterations)
         bool st_debug = false;          // DVO_ST_DEBUG (experiment builds): fallback decisions on stderr
+        double st_tol = 5e-6;           // (experiment builds: DVO_ST_TOL) one-pass Student-t iterations are kept within this of the increment
         int exp_taps = 0;               // DVO_EXP_TAPS=1..4: dvo_normal_equations (V1, unweighted) runs an experimental tap
                                         // formulation of the reduction (dvo_exp_taps.inc; tools/exp_taps.py); never the solve path
     } knobs;
@@ -411,6 +428,7 @@ int prepare_slot(dvo_ctx* ctx, int slot, int w, int h, int levels)
         HIP_TRY(ctx, hipMemsetAsync(ctx->d_slots + (size_t)slot * ctx->slot_stride, 0, ctx->slot_stride, ctx->stream));
     }
     s.w = w; s.h = h; s.levels = levels; s.ready = false;
+    s.epoch = ++ctx->upload_epoch;
     s.lists = ctx->have_camera;      // the valid-point lists built at ingest hold z = depth * depth_scale
     return DVO_OK;
 }
@@ -469,6 +487,10 @@ int dvo_create(int device, int max_w, int max_h, int max_levels, int n_slots, in
     CREATE_TRY(hipMalloc((void**)&ctx->d_wparam, np * sizeof(double)));
     CREATE_TRY(hipMalloc((void**)&ctx->d_active, np * sizeof(int)));
     CREATE_TRY(hipMalloc((void**)&ctx->d_irls_done, np * sizeof(int)));
+    CREATE_TRY(hipMalloc((void**)&ctx->d_pair_flags, np * sizeof(int)));
+    CREATE_TRY(hipMemset(ctx->d_pair_flags, 0, np * sizeof(int)));
+    CREATE_TRY(hipHostMalloc((void**)&ctx->h_pair_flags, np * sizeof(int)));
+    CREATE_TRY(hipMalloc((void**)&ctx->d_trace_row, np * sizeof(int)));
     CREATE_TRY(hipMalloc((void**)&ctx->d_frame_slots, (size_t)n_slots * sizeof(int)));
     CREATE_TRY(hipHostMalloc((void**)&ctx->h_frame_slots, 4 * (size_t)n_slots * sizeof(int)));
     for (int i = 0; i < 4; ++i) CREATE_TRY(hipEventCreateWithFlags(&ctx->ev_fs[i], hipEventDisableTiming));
@@ -511,7 +533,6 @@ int dvo_create(int device, int max_w, int max_h, int max_levels, int n_slots, in
         ctx->knobs.no_rcache = getenv("DVO_NO_RCACHE") != nullptr;
         ctx->knobs.ingest_unfused = getenv("DVO_INGEST_UNFUSED") != nullptr;
         ctx->knobs.st_exact = getenv("DVO_ST_EXACT") != nullptr;
-        ctx->knobs.st_small_exact = getenv("DVO_ST_SMALL_EXACT") != nullptr;
         e = getenv("DVO_SMALL_MAX_PIX");
         if (e) ctx->knobs.small_max_pix = atoi(e);
         e = getenv("DVO_SMALL_THREADS");
@@ -525,6 +546,8 @@ int dvo_create(int device, int max_w, int max_h, int max_levels, int n_slots, in
         e = getenv("DVO_TARGET_BLOCKS");
         if (e && atoi(e) > 0) ctx->knobs.target_blocks = atoi(e);
         ctx->knobs.st_debug = getenv("DVO_ST_DEBUG") != nullptr;
+        e = getenv("DVO_ST_TOL");
+        if (e && atof(e) > 0.0) ctx->knobs.st_tol = atof(e);
         if (getenv("DVO_SMALL_STAMPS") != nullptr) {
             CREATE_TRY(hipMalloc((void**)&ctx->d_small_stamps, (size_t)max_pairs * 8 * sizeof(unsigned long long)));
             CREATE_TRY(hipMemset(ctx->d_small_stamps, 0, (size_t)max_pairs * 8 * sizeof(unsigned long long)));
@@ -557,11 +580,11 @@ void dvo_destroy(dvo_ctx* ctx)
     if (ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);
     void* dev[] = {ctx->d_slots, ctx->d_prev, ctx->d_cur, ctx->d_T, ctx->d_Tinit, ctx->d_wparam, ctx->d_active, ctx->d_partials,
                    ctx->d_out, ctx->d_state, ctx->d_xi, ctx->d_iters, ctx->d_err, ctx->d_stage_img, ctx->d_dense, ctx->d_trace, ctx->d_frame_slots, ctx->d_prior, ctx->d_batch_stage,
-                   ctx->d_list_count, ctx->d_seg_counts, ctx->d_rcache, ctx->d_scale1, ctx->d_scale2, ctx->d_irls_done,
+                   ctx->d_list_count, ctx->d_seg_counts, ctx->d_rcache, ctx->d_scale1, ctx->d_scale2, ctx->d_irls_done, ctx->d_pair_flags, ctx->d_trace_row,
                    ctx->d_exp_gradh, ctx->d_exp_ipl, ctx->d_partials2, ctx->d_inexact, ctx->d_small_stamps};
     for (void* p : dev) if (p) (void)hipFree(p);
     void* host[] = {ctx->hs.prev, ctx->hs.cur, ctx->hs.T, ctx->hs.wparam, ctx->hs.out, ctx->hs.xi, ctx->hs.iters, ctx->hs.err, ctx->h_frame_slots, ctx->h_prior,
-                    ctx->h_inexact};
+                    ctx->h_inexact, ctx->h_pair_flags};
     for (void* p : host) if (p) (void)hipHostFree(p);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
@@ -1123,6 +1146,9 @@ static int record_solve(dvo_ctx* ctx, const SolveKey& k, const float* d_init)
     const double lambda0 = 1.0 / 25.0;                      // TDistributionWeighter: initial_sigma = 5 (t_weighter.py:11-15)
     HIP_TRY(ctx, hipMemsetAsync(ctx->d_irls_done, 0, (size_t)n_pairs * sizeof(int), ctx->stream));
     if (ctx->d_inexact) HIP_TRY(ctx, hipMemsetAsync(ctx->d_inexact, 0, 8 * sizeof(int), ctx->stream));
+    if (weight_mode == DVO_WEIGHT_STUDENT_T) HIP_TRY(ctx, hipMemsetAsync(ctx->d_pair_flags, 0, (size_t)n_pairs * sizeof(int), ctx->stream));
+    const int* trace_row = k.trace_rows ? ctx->d_trace_row : nullptr;
+    int* pair_flags = (weight_mode == DVO_WEIGHT_STUDENT_T) ? ctx->d_pair_flags : nullptr;
     HIP_TRY(ctx, dvo_launch_init_state(ctx->d_state, ctx->d_T, d_init, n_pairs, lambda0,
                                        (k.inv_sigma > 0.0 && k.has_last) ? ctx->d_prior : nullptr, ctx->stream));
     // The coarsest levels (at most knobs.small_max_pix pixels each) run in ONE persistent launch, a workgroup per pair
@@ -1140,7 +1166,9 @@ static int record_solve(dvo_ctx* ctx, const SolveKey& k, const float* d_init)
         // (not with a Student-t weighting: the persistent kernel runs the reference's IRLS loop as written, the per-iteration
         // launches a fixed number of passes, and a pair must not get a different lambda because of the size of its batch)
         const bool student_t = (weight_mode == DVO_WEIGHT_STUDENT_T || weight_mode == DVO_WEIGHT_STUDENT_T_MEAN);
-        const int max_pix = (n_pairs <= 16 && !student_t) ? (ctx->knobs.small_max_pix < 4800 ? ctx->knobs.small_max_pix : 4800) : ctx->knobs.small_max_pix;
+        // (st_exact == 2, the Student-t fallback: EVERY level here, because this kernel runs the reference's IRLS loop as written)
+        const int max_pix = (k.st_exact == 2) ? INT_MAX
+                          : (n_pairs <= 16 && !student_t) ? (ctx->knobs.small_max_pix < 4800 ? ctx->knobs.small_max_pix : 4800) : ctx->knobs.small_max_pix;
         while (level - n >= 0 && n < DVO_SMALL_LEVELS && g[level - n].npix <= max_pix) {
             sp.level_id[n] = level - n;
             sp.level_iters[n] = k.level_iters[level - n];
@@ -1163,8 +1191,7 @@ static int record_solve(dvo_ctx* ctx, const SolveKey& k, const float* d_init)
             sp.wparam = ctx->d_wparam;
             sp.rcache = (weight_mode == DVO_WEIGHT_STUDENT_T || weight_mode == DVO_WEIGHT_STUDENT_T_MEAN) ? ctx->d_rcache : nullptr;
             sp.student_t_mean = (weight_mode == DVO_WEIGHT_STUDENT_T_MEAN) ? 1 : 0;
-            sp.st_one_pass = (weight_mode == DVO_WEIGHT_STUDENT_T && !k.st_exact && !ctx->knobs.st_solve_phases && !ctx->knobs.st_small_exact) ? 1 : 0;
-            sp.st_counts = (sp.st_one_pass && ctx->d_inexact) ? ctx->d_inexact + 4 : nullptr;
+            sp.trace_row = trace_row;
             sp.rcache_stride = (size_t)ctx->max_w * ctx->max_h;
             sp.tolerance = tolerance;
             sp.max_increased = max_increased_steps_allowed;
@@ -1215,6 +1242,11 @@ static int record_solve(dvo_ctx* ctx, const SolveKey& k, const float* d_init)
         sp.trace = ctx->d_trace;
         sp.trace_stride = DVO_STRIDE + 18;
         sp.trace_cap = ctx->trace_cap;
+        sp.trace_row = trace_row;
+        sp.st_tol = ctx->knobs.st_tol;
+        sp.pair_flags = pair_flags;
+        sp.scale1 = nullptr;
+        sp.scale2 = nullptr;
         sp.irls_done = nullptr;
         sp.phase = 0;
         sp.partials2 = nullptr;
@@ -1226,14 +1258,18 @@ static int record_solve(dvo_ctx* ctx, const SolveKey& k, const float* d_init)
         // ordinary images (>= 320x240); a solve whose bound fails is repeated with the three-pass form by dvo_solve_batch_fetch.
         const bool moment_form = (weight_mode == DVO_WEIGHT_STUDENT_T) && !k.st_exact && !ctx->knobs.st_solve_phases &&
                                  variant == DVO_VARIANT_V1 && ctx->d_partials2 != nullptr && p.g.npix >= 76800;
-        HIP_TRY(ctx, dvo_launch_level_begin(ctx->d_state, ctx->d_active, ctx->d_wparam, n_pairs, weight_mode, lambda0, ctx->stream));
+        HIP_TRY(ctx, dvo_launch_level_begin(ctx->d_state, ctx->d_active, ctx->d_wparam, n_pairs, weight_mode, lambda0, moment_form ? 1 : 0, ctx->stream));
         for (int it = 0; it < k.level_iters[level]; ++it) {
             if (moment_form) {
-                // first three iterations of the level: moment form (no lambda history to extrapolate from yet); later ones: weights
-                // under the lambda extrapolated from the three iterations before, cheaper by a whole second set of sums
+                // Both one-pass forms evaluate the weights under a guessed lambda and correct the sums to first order in what the
+                // guess was off by (student_t_moment_combine / student_t_predicted_combine).  The CORRECTED form (second record:
+                // derivatives of H and b) is second-order accurate whatever the guess: first three iterations of a level (no lambda
+                // history to extrapolate from yet) and every iteration of the levels below 640x480, where the lambda of a few ten
+                // thousand points is not predictable to the 1e-4 the cheaper form needs.  The PREDICTED form (only b corrected,
+                // six extra sums instead of 30) from the fourth iteration on at the large levels.
                 p.partials2 = ctx->d_partials2;
                 p.lambda0 = (float)lambda0;
-                sp.predicted = (it > 2) ? 1 : 0;
+                sp.predicted = (it > 2 && p.g.npix >= 640 * 480) ? 1 : 0;
                 HIP_TRY(ctx, launch_reduce_profiled(ctx, p, level, variant, sp.predicted ? 5 : 4, 0));
                 sp.partials2 = ctx->d_partials2;
                 sp.inexact = ctx->d_inexact;
@@ -1254,6 +1290,8 @@ static int record_solve(dvo_ctx* ctx, const SolveKey& k, const float* d_init)
                     HIP_TRY(ctx, dvo_launch_scale_cached(p, ctx->stream));
                     p.scale_out = nullptr;
                     p.scale2 = ctx->d_scale2;
+                    sp.scale1 = ctx->d_scale1;          // the control launch checks the two-pass shape of the reference's loop
+                    sp.scale2 = ctx->d_scale2;
                 } else {
                     // a control launch after every pass (k_solve, phase > 0) updates lambda and the per-pair converged flag; the
                     // workgroups of a converged pair leave the remaining passes at once
@@ -1275,6 +1313,9 @@ static int record_solve(dvo_ctx* ctx, const SolveKey& k, const float* d_init)
             p.scale2 = nullptr;
             sp.phase = 0;
             HIP_TRY(ctx, dvo_launch_solve(sp, ctx->stream));
+            sp.scale1 = nullptr;
+            sp.scale2 = nullptr;
+            sp.irls_done = nullptr;
         }
     }
     HIP_TRY(ctx, dvo_launch_finish(ctx->d_state, n_pairs, ctx->d_xi, ctx->d_iters, ctx->d_err, ctx->stream));
@@ -1347,9 +1388,21 @@ int dvo_solve_batch_enqueue(dvo_ctx* ctx, int n_pairs, const int* prev_slot, con
     key.has_last = ctx->prior_has_last ? 1 : 0;
     for (int l = 0; l < levels && l < DVO_MAX_LEVELS; ++l) key.level_iters[l] = ctx->level_iters_set ? ctx->level_iters[l] : max_iterations;
     key.st_exact = ctx->knobs.st_exact ? 1 : 0;
+    key.trace_rows = 0;
     ctx->last_key = key;
     ctx->last_has_init = (T_init != nullptr);
-    ctx->last_moment = (weight_mode == DVO_WEIGHT_STUDENT_T) && !key.st_exact && ctx->d_partials2 != nullptr;
+    ctx->last_moment = (weight_mode == DVO_WEIGHT_STUDENT_T) && variant != DVO_VARIANT_V3;
+    if (ctx->last_moment) {
+        // host copies for the per-pair fallback of dvo_solve_batch_fetch
+        dvo_ctx::LastSolve& L = ctx->last;
+        L.prev.assign(prev_slot, prev_slot + n_pairs);
+        L.cur.assign(cur_slot, cur_slot + n_pairs);
+        L.ep_prev.resize(n_pairs);
+        L.ep_cur.resize(n_pairs);
+        for (int i = 0; i < n_pairs; ++i) { L.ep_prev[i] = ctx->slots[prev_slot[i]].epoch; L.ep_cur[i] = ctx->slots[cur_slot[i]].epoch; }
+        if (T_init) L.Tinit.assign(T_init, T_init + (size_t)n_pairs * 12); else L.Tinit.clear();
+        if (key.inv_sigma > 0.0 && key.has_last) L.prior.assign(ctx->h_prior, ctx->h_prior + (size_t)n_pairs * 7); else L.prior.clear();
+    }
     return enqueue_solve(ctx, key, d_init);
 }
 
@@ -1381,39 +1434,119 @@ static int enqueue_solve(dvo_ctx* ctx, const SolveKey& key, const float* d_init)
     return record_solve(ctx, key, d_init);
 }
 
+// copies the device-side results of the solve enqueued last into the page-locked staging buffers and waits for them
+static int fetch_results(dvo_ctx* ctx, int n_pairs, bool student_t)
+{
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->hs.T, ctx->d_T, (size_t)n_pairs * 12 * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->hs.xi, ctx->d_xi, (size_t)n_pairs * 6 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->hs.iters, ctx->d_iters, (size_t)n_pairs * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->hs.err, ctx->d_err, (size_t)n_pairs * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    if (student_t) {
+        if (ctx->d_inexact) HIP_TRY(ctx, hipMemcpyAsync(ctx->h_inexact, ctx->d_inexact, 8 * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipMemcpyAsync(ctx->h_pair_flags, ctx->d_pair_flags, (size_t)n_pairs * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    }
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return DVO_OK;
+}
+
+// Student-t of the reference: the pairs `idx` of the solve enqueued last, solved again as a compacted batch in the form `st_exact`
+// (1: passes as written at the per-iteration levels; 2: every level in the persistent kernel = the reference's loop itself), results
+// scattered into the caller's arrays.  On return h_pair_flags[0..k) holds the flags of the re-solve (compacted order).
+static int resolve_pairs(dvo_ctx* ctx, const std::vector<int>& idx, int st_exact, float* T_out, double* xi_out, int* iters_out, double* err_out)
+{
+    const dvo_ctx::LastSolve& L = ctx->last;
+    const int k = (int)idx.size();
+    std::vector<int> prev(k), cur(k);
+    for (int i = 0; i < k; ++i) {
+        const int j = idx[i];
+        prev[i] = L.prev[j];
+        cur[i] = L.cur[j];
+        // the frames must still be the ones the solve was enqueued on (include/dvo_hip.h, dvo_solve_batch_enqueue)
+        if (ctx->slots[prev[i]].epoch != L.ep_prev[j] || ctx->slots[cur[i]].epoch != L.ep_cur[j] || !ctx->slots[prev[i]].ready || !ctx->slots[cur[i]].ready)
+            return fail(ctx, DVO_ERR_BAD_STATE, "Student-t solve: pair %d must be solved again with the passes as written, but slot %d or %d was uploaded "
+                        "again between dvo_solve_batch_enqueue and dvo_solve_batch_fetch", j, prev[i], cur[i]);
+    }
+    int rc = stage_pairs(ctx, k, prev.data(), cur.data(), nullptr, nullptr);
+    if (rc) return rc;
+    const float* d_init = nullptr;
+    if (!L.Tinit.empty()) {
+        for (int i = 0; i < k; ++i) memcpy(ctx->hs.T + (size_t)i * 12, L.Tinit.data() + (size_t)idx[i] * 12, 12 * sizeof(float));
+        HIP_TRY(ctx, hipMemcpyAsync(ctx->d_Tinit, ctx->hs.T, (size_t)k * 12 * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+        d_init = ctx->d_Tinit;
+    }
+    // (page-locked scratch for the small compacted arrays: hs.wparam holds max_pairs doubles, unused by the solve path)
+    if (!L.prior.empty()) {
+        std::vector<double> pr((size_t)k * 7);
+        for (int i = 0; i < k; ++i) memcpy(pr.data() + (size_t)i * 7, L.prior.data() + (size_t)idx[i] * 7, 7 * sizeof(double));
+        HIP_TRY(ctx, hipMemcpy(ctx->d_prior, pr.data(), pr.size() * sizeof(double), hipMemcpyHostToDevice));
+    }
+    SolveKey key = ctx->last_key;
+    key.n_pairs = k;
+    key.st_exact = st_exact;
+    if (ctx->d_trace) {
+        key.trace_rows = 1;
+        HIP_TRY(ctx, hipMemcpy(ctx->d_trace_row, idx.data(), (size_t)k * sizeof(int), hipMemcpyHostToDevice));
+        // the re-solved pairs' rows start again (iterations beyond the new count would otherwise keep the first solve's records)
+        const size_t row = (size_t)ctx->trace_cap * (DVO_STRIDE + 18) * sizeof(double);
+        for (int i = 0; i < k; ++i) HIP_TRY(ctx, hipMemsetAsync(reinterpret_cast<char*>(ctx->d_trace) + (size_t)idx[i] * row, 0, row, ctx->stream));
+    }
+    rc = enqueue_solve(ctx, key, d_init);
+    if (rc) return rc;
+    rc = fetch_results(ctx, k, true);
+    if (rc) return rc;
+    for (int i = 0; i < k; ++i) {
+        const int j = idx[i];
+        if (T_out) memcpy(T_out + (size_t)j * 12, ctx->hs.T + (size_t)i * 12, 12 * sizeof(float));
+        if (xi_out) memcpy(xi_out + (size_t)j * 6, ctx->hs.xi + (size_t)i * 6, 6 * sizeof(double));
+        if (iters_out) iters_out[j] = ctx->hs.iters[i];
+        if (err_out) err_out[j] = ctx->hs.err[i];
+    }
+    if (!L.prior.empty())           // leave the whole batch's prior where dvo_set_prior put it
+        HIP_TRY(ctx, hipMemcpy(ctx->d_prior, L.prior.data(), L.prior.size() * sizeof(double), hipMemcpyHostToDevice));
+    return DVO_OK;
+}
+
 int dvo_solve_batch_fetch(dvo_ctx* ctx, int n_pairs, float* T_out, double* xi_out, int* iters_out, double* err_out)
 {
     if (!ctx) return DVO_ERR_INVALID_ARG;
     if (n_pairs <= 0 || n_pairs > ctx->max_pairs) return fail(ctx, DVO_ERR_INVALID_ARG, "n_pairs %d outside [1,%d]", n_pairs, ctx->max_pairs);
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    if (T_out) HIP_TRY(ctx, hipMemcpyAsync(ctx->hs.T, ctx->d_T, (size_t)n_pairs * 12 * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
-    if (xi_out) HIP_TRY(ctx, hipMemcpyAsync(ctx->hs.xi, ctx->d_xi, (size_t)n_pairs * 6 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-    if (iters_out) HIP_TRY(ctx, hipMemcpyAsync(ctx->hs.iters, ctx->d_iters, (size_t)n_pairs * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
-    if (err_out) HIP_TRY(ctx, hipMemcpyAsync(ctx->hs.err, ctx->d_err, (size_t)n_pairs * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-    if (ctx->last_moment) HIP_TRY(ctx, hipMemcpyAsync(ctx->h_inexact, ctx->d_inexact, 8 * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    if (ctx->last_moment) { ctx->st_small_kept += ctx->h_inexact[4]; ctx->st_small_redone += ctx->h_inexact[5]; }
-    if (ctx->last_moment && ctx->knobs.st_debug && ctx->h_inexact[5])
-        fprintf(stderr, "dvo: persistent levels: %d one-pass iterations kept, %d run again (%d for the IRLS shape / series, %d at the coarsest level)\n",
-                ctx->h_inexact[4], ctx->h_inexact[5], ctx->h_inexact[6], ctx->h_inexact[7]);
-    if (ctx->last_moment && *ctx->h_inexact != 0) {
-        // an iteration of this batch did not meet the moment form's bound (or its IRLS would not take exactly two passes): the same
-        // solve again with the reference's passes as written (slot ids and initial poses are still in their device buffers)
-        ctx->last_moment = false;
-        ctx->st_fallbacks += 1;
-        if (ctx->knobs.st_debug)
-            fprintf(stderr, "dvo: Student-t one-pass form rejected in %d iteration(s) (IRLS shape %d, moment bound %d, predicted bound %d): repeating with the three-pass form\n",
-                    ctx->h_inexact[0], ctx->h_inexact[1], ctx->h_inexact[2], ctx->h_inexact[3]);
-        SolveKey key = ctx->last_key;
-        key.st_exact = 1;
-        int rc = enqueue_solve(ctx, key, ctx->last_has_init ? ctx->d_Tinit : nullptr);
-        if (rc) return rc;
-        return dvo_solve_batch_fetch(ctx, n_pairs, T_out, xi_out, iters_out, err_out);
-    }
+    const bool student_t = ctx->last_moment && n_pairs == ctx->last_key.n_pairs;
+    int rc = fetch_results(ctx, n_pairs, student_t);
+    if (rc) return rc;
     if (T_out) memcpy(T_out, ctx->hs.T, (size_t)n_pairs * 12 * sizeof(float));
     if (xi_out) memcpy(xi_out, ctx->hs.xi, (size_t)n_pairs * 6 * sizeof(double));
     if (iters_out) memcpy(iters_out, ctx->hs.iters, (size_t)n_pairs * sizeof(int));
     if (err_out) memcpy(err_out, ctx->hs.err, (size_t)n_pairs * sizeof(double));
+    if (!student_t) return DVO_OK;
+    ctx->last_moment = false;           // the counters below are added once per enqueued solve, whatever the caller fetches again
+    // Per-pair fallback.  A pair with an iteration whose one-pass bound was not met (flag 1) is solved again with the passes as
+    // written at the per-iteration levels; a pair whose IRLS does not have the two-pass shape those levels evaluate (flag 2, from
+    // either solve) is solved again by the persistent kernel at every level, which runs the reference's loop (until |d lambda| <
+    // 1e-3, at most 50 passes).  Only the flagged pairs are solved again, as one compacted batch per form; the others keep their
+    // results.
+    std::vector<int> bound_only, shape;
+    for (int i = 0; i < n_pairs; ++i) {
+        if (ctx->h_pair_flags[i] & 2) shape.push_back(i);
+        else if (ctx->h_pair_flags[i] & 1) bound_only.push_back(i);
+    }
+    if (bound_only.empty() && shape.empty()) return DVO_OK;
+    ctx->st_fallbacks += 1;
+    ctx->st_fallback_pairs += (int64_t)(bound_only.size() + shape.size());
+    if (ctx->knobs.st_debug)
+        fprintf(stderr, "dvo: Student-t: %zu pair(s) of %d solved again with the passes as written, %zu by the reference's loop (iterations flagged: %d; "
+                        "IRLS shape %d, moment bound %d, predicted bound %d)\n", bound_only.size(), n_pairs, shape.size(),
+                ctx->h_inexact ? ctx->h_inexact[0] : 0, ctx->h_inexact ? ctx->h_inexact[1] : 0, ctx->h_inexact ? ctx->h_inexact[2] : 0, ctx->h_inexact ? ctx->h_inexact[3] : 0);
+    if (!bound_only.empty()) {
+        rc = resolve_pairs(ctx, bound_only, 1, T_out, xi_out, iters_out, err_out);
+        if (rc) return rc;
+        for (size_t i = 0; i < bound_only.size(); ++i)
+            if (ctx->h_pair_flags[i] & 2) shape.push_back(bound_only[i]);        // ... and the passes as written found a third pass
+    }
+    if (!shape.empty()) {
+        rc = resolve_pairs(ctx, shape, 2, T_out, xi_out, iters_out, err_out);
+        if (rc) return rc;
+    }
     return DVO_OK;
 }
 
@@ -1437,11 +1570,10 @@ int dvo_student_t_fallbacks(const dvo_ctx* ctx, int64_t* count)
     return DVO_OK;
 }
 
-int dvo_student_t_small_level_counts(const dvo_ctx* ctx, int64_t* kept, int64_t* redone)
+int dvo_student_t_fallback_pairs(const dvo_ctx* ctx, int64_t* pairs)
 {
-    if (!ctx || !kept || !redone) return DVO_ERR_INVALID_ARG;
-    *kept = ctx->st_small_kept;
-    *redone = ctx->st_small_redone;
+    if (!ctx || !pairs) return DVO_ERR_INVALID_ARG;
+    *pairs = ctx->st_fallback_pairs;
     return DVO_OK;
 }
 

@@ -103,6 +103,7 @@ struct DvoPairState {
     double lam_hist[3]; // Student-t one-pass forms: the converged lambda of the last three iterations of this level ([0] newest)
     int lam_n;          // ... how many of them are valid (reset at every level)
     int pad2;
+    double lam_err;     // ... and how far off (relative) the prediction of the last evaluated iteration's lambda was (1: none yet)
 };
 
 struct DvoSolveParams {
@@ -126,12 +127,21 @@ struct DvoSolveParams {
     int* irls_done;             // [n_pairs] see DvoReduceParams, or null
     double* trace;              // optional [n_pairs][max_trace][DVO_STRIDE+8] per-iteration records, or null
     int trace_stride, trace_cap;
+    const int* trace_row;       // trace row of pair i (a re-solve of a compacted subset writes into its pairs' original rows), or null: i
+    int* pair_flags;            // Student-t of the reference, per pair: |= 1 an iteration's one-pass bound was not met (the pair is solved
+                                // again with the passes as written), |= 2 the IRLS of an iteration would not take exactly the two passes
+                                // the per-iteration levels evaluate (the pair is solved again by the persistent kernel, which runs the
+                                // reference's loop); or null
+    const double* scale1;       // Student-t, passes as written without control launches between them: the per-workgroup sums of the two
+    const double* scale2;       // scale passes of this iteration (the control step checks the two-pass shape from them), or null
+    double st_tol;              // Student-t one-pass forms: an iteration is kept when the bound on what its form drops is within st_tol of
+                                // the increment (2-norm); 5e-6 = half the parity tolerance
 };
 
 // Persistent small-level Gauss-Newton kernel (k_gn_small): ONE workgroup per frame pair runs every iteration of up to
 // DVO_SMALL_LEVELS consecutive coarse pyramid levels — reduction, 6x6 solve, SE(3) update and stop rules — without
 // leaving the kernel (no launch per iteration, no partial sums through HBM).
-#define DVO_SMALL_LEVELS 4
+#define DVO_SMALL_LEVELS 8               // == DVO_MAX_LEVELS: the Student-t fallback runs EVERY level of its pairs here
 struct DvoSmallParams {
     const uint8_t* slots;
     size_t slot_stride;
@@ -158,11 +168,10 @@ struct DvoSmallParams {
     double inv_sigma;
     double lambda0;              // Student-t: 1 / initial_sigma^2
     int student_t_mean;          // Student-t scale = mean (proper) instead of the reference's sum (quirk Q3)
-    int st_one_pass;             // Student-t of the reference: iterations >= 3 of a level in one pass under a predicted lambda (else as written)
-    int* st_counts;              // diagnostic, or null: [0] += one-pass iterations kept, [1] += one-pass iterations run again as written
     int* irls_done;              // unused here (the IRLS loop runs inside the kernel); null
     double* trace;
     int trace_stride, trace_cap;
+    const int* trace_row;        // see DvoSolveParams
     unsigned long long* stamps;  // diagnostic (DVO_SMALL_STAMPS): [n_pairs][8] shader-clock ticks thread 0 of the workgroup spent in
                                  // {record loops, wave reduction + barrier, cross-wave sum + barrier, control step + barrier,
                                  //  Student-t scale passes, whole kernel}; or null
@@ -196,7 +205,7 @@ hipError_t dvo_launch_dense(const DvoDenseParams& p, int variant, hipStream_t s)
 hipError_t dvo_launch_init_state(DvoPairState* st, float* T, const float* T_init, int n_pairs, double lambda0,
                                  const double* prior_qt, hipStream_t s);
 hipError_t dvo_launch_level_begin(DvoPairState* st, int* active, double* wparam, int n_pairs, int weight_mode,
-                                  double lambda0, hipStream_t s);
+                                  double lambda0, int one_pass, hipStream_t s);
 hipError_t dvo_launch_solve(const DvoSolveParams& p, hipStream_t s);
 hipError_t dvo_launch_gn_small(const DvoSmallParams& p, int variant, int threads, hipStream_t s);
 hipError_t dvo_launch_debug_divide(const float* a, const float* b, float* out, float* ref, int n, hipStream_t s);

@@ -962,7 +962,7 @@ template <int NTERMS = DVO_NACC>
 __device__ __forceinline__ void block_reduce_terms_buf(const float* acc, double* out, float* tbuf /* LDS [DVO_REDUCE_TBUF_FLOATS] */,
                                                        unsigned long long t0 = 0, unsigned long long r0 = 0)
 {
-    static_assert(NTERMS == DVO_NACC || NTERMS == DVO_STRIDE, "30 sums, or all 32 slots of the record");
+    static_assert(NTERMS == DVO_NACC || NTERMS == DVO_STRIDE || NTERMS == 6, "30 sums, all 32 slots of the record, or 6 extra sums");
     constexpr int ROW = 8 * 33;                          // 8 segments of 32 values + 1 pad each
     constexpr int HALF = NTERMS / 2;
     const int t = threadIdx.x;
@@ -985,7 +985,7 @@ __device__ __forceinline__ void block_reduce_terms_buf(const float* acc, double*
         sgm += __shfl_xor(sgm, 4, 64);
         if (t < HALF * 8 && segi == 0) out[round * HALF + term] = sgm;
     }
-    if (NTERMS == DVO_STRIDE) return;
+    if (NTERMS == DVO_STRIDE || NTERMS == 6) return;
 #ifdef DVO_CLOCK_PROBE
     if (t == 30) out[t] = (double)(__builtin_amdgcn_s_memtime() - t0);
     if (t == 31) out[t] = (double)(__builtin_amdgcn_s_memrealtime() - r0);
@@ -1080,8 +1080,9 @@ __global__ __launch_bounds__(DVO_BLOCK, (VARIANT == 2) ? 2 : DVO_REDUCE_WAVES_PE
         }
         wpar = (float)lam;
     }
-    // WMODE 4 / 5: the first scale pass runs under the CONSTANT lambda0 (p.lambda0); wparam[pair] (wpar) is the predicted lambda of
-    // this iteration (used by WMODE 5 only: from the second iteration of a level on it no longer holds lambda0)
+    // WMODE 4 / 5: the first scale pass runs under the CONSTANT lambda0 (p.lambda0); wparam[pair] (wpar) is the GUESSED lambda the
+    // weights of this iteration are evaluated under (4: 0 at the first level, a quarter of the level before's last lambda at the
+    // first iteration of a level, then the last / the linearly extrapolated lambda; 5: the geometric extrapolation of the last three)
     const float lam0 = (WMODE == 4 || WMODE == 5) ? p.lambda0 : 0.0f;
 
     float acc[NACC];
@@ -1091,6 +1092,10 @@ __global__ __launch_bounds__(DVO_BLOCK, (VARIANT == 2) ? 2 : DVO_REDUCE_WAVES_PE
     float acc2[(WMODE == 4) ? DVO_NACC : 1];
 #pragma unroll
     for (int i = 0; i < ((WMODE == 4) ? DVO_NACC : 1); ++i) acc2[i] = 0.0f;
+    // WMODE 5: b1 = sum w^2 r^3 J (see below); lands in slots 21..26 of the second record, where WMODE 4 puts its b1
+    float acc3[(WMODE == 5) ? 6 : 1];
+#pragma unroll
+    for (int i = 0; i < ((WMODE == 5) ? 6 : 1); ++i) acc3[i] = 0.0f;
 
     // Work items are the records of the previous frame's valid-point list (depth != 0, raster order, built once at
     // ingest): no validity test, no pixel-index arithmetic and no empty lanes inside the Gauss-Newton loop.  A wave
@@ -1185,11 +1190,11 @@ __global__ __launch_bounds__(DVO_BLOCK, (VARIANT == 2) ? 2 : DVO_REDUCE_WAVES_PE
                     rkeep[j] = r;
                 } else {
                     float wt = 1.0f;
-                    if (WMODE == 1 || WMODE == 5) wt = 6.0f * fast_rcp(fmaf(r2, wpar, 5.0f));   // t_weighter.py:34
+                    if (WMODE == 1 || WMODE == 4 || WMODE == 5) wt = 6.0f * fast_rcp(fmaf(r2, wpar, 5.0f));   // t_weighter.py:34 (4 / 5: under the guessed lambda)
                     if (WMODE == 2) { const float ar = fabsf(r); wt = (ar <= wpar) ? 1.0f : wpar * fast_rcp(ar); }
                     float wj[6];
 #pragma unroll
-                    for (int k = 0; k < 6; ++k) wj[k] = (WMODE == 0 || WMODE == 4) ? o.J[k] : wt * o.J[k];
+                    for (int k = 0; k < 6; ++k) wj[k] = (WMODE == 0) ? o.J[k] : wt * o.J[k];
                     int q = 0;
 #pragma unroll
                     for (int a = 0; a < 6; ++a)
@@ -1197,31 +1202,39 @@ __global__ __launch_bounds__(DVO_BLOCK, (VARIANT == 2) ? 2 : DVO_REDUCE_WAVES_PE
                         for (int b = a; b < 6; ++b) { acc[q] = fmaf(wj[a], o.J[b], acc[q]); ++q; }
 #pragma unroll
                     for (int k = 0; k < 6; ++k) acc[21 + k] = fmaf(wj[k], r, acc[21 + k]);
-                    if (WMODE != 5) acc[27] = fmaf((WMODE == 0 || WMODE == 4) ? r : wt * r, r, acc[27]);
+                    if (WMODE != 5) acc[27] = fmaf((WMODE == 0 || WMODE == 4) ? r : wt * r, r, acc[27]);   // (4: the plain moment sum r^2)
                     acc[28] += 1.0f;
                     if (WMODE == 1 || WMODE == 2 || WMODE == 5) acc[29] += r2;             // WMODE 0: copied from acc[27] after the loop
                     if constexpr (WMODE == 5) {
                         // beside the system weighted with the predicted lambda: the first scale pass under the constant lambda0
-                        // (exact per point) and the moments r^4, r^6 from which the control step rebuilds the second pass
+                        // (exact per point), the moments r^4, r^6 from which the control step rebuilds the second pass, and
+                        // b1 = sum w^2 r^3 J, the derivative of J^T W r with respect to lambda (x -6): the control step corrects the
+                        // right-hand side to first order in (lambda2 - predicted lambda)
                         acc[27] += r2 * (6.0f * fast_rcp(fmaf(r2, lam0, 5.0f)));
                         const float r4 = r2 * r2;
                         acc[30] += r4;
                         acc[31] = fmaf(r4, r2, acc[31]);
+                        const float u = (wt * r2) * r;
+#pragma unroll
+                        for (int k = 0; k < 6; ++k) acc3[k] = fmaf(wj[k], u, acc3[k]);
                     }
                     if constexpr (WMODE == 4) {
                         // first scale pass under the constant lambda0 (t_weighter.py:23, :43-45), exact per point
                         acc[29] += r2 * (6.0f * fast_rcp(fmaf(r2, lam0, 5.0f)));
-                        // r^2-weighted normal equations and the even moments r^4, r^6, r^8
+                        // derivatives with respect to lambda (x -6) of the weighted sums above: H1 = sum w^2 r^2 J J^T,
+                        // b1 = sum w^2 r^3 J; and the even moments r^4, r^6, r^8
+                        const float wr = wt * r;
                         float rj[6];
 #pragma unroll
-                        for (int k = 0; k < 6; ++k) rj[k] = r * o.J[k];
+                        for (int k = 0; k < 6; ++k) rj[k] = wr * o.J[k];
                         int q2 = 0;
 #pragma unroll
                         for (int a = 0; a < 6; ++a)
 #pragma unroll
                             for (int b = a; b < 6; ++b) { acc2[q2] = fmaf(rj[a], rj[b], acc2[q2]); ++q2; }
+                        const float wr2 = wt * r2;
 #pragma unroll
-                        for (int k = 0; k < 6; ++k) acc2[21 + k] = fmaf(rj[k], r2, acc2[21 + k]);
+                        for (int k = 0; k < 6; ++k) acc2[21 + k] = fmaf(rj[k], wr2, acc2[21 + k]);
                         const float r4 = r2 * r2;
                         acc2[27] += r4;
                         acc2[28] = fmaf(r4, r2, acc2[28]);
@@ -1261,10 +1274,15 @@ __global__ __launch_bounds__(DVO_BLOCK, (VARIANT == 2) ? 2 : DVO_REDUCE_WAVES_PE
         }
     } else {
         double* out = p.partials + ((size_t)pair * p.blocks_per_pair + blk) * DVO_STRIDE;
-        block_reduce_terms<NACC>(acc, out, probe_t0, probe_r0);
+        __shared__ float tbuf[DVO_REDUCE_TBUF_FLOATS];     // one transpose buffer for every reduction of the launch
+        block_reduce_terms_buf<NACC>(acc, out, tbuf, probe_t0, probe_r0);
         if constexpr (WMODE == 4) {
             __syncthreads();                               // the transpose buffer is reused
-            block_reduce_terms(acc2, p.partials2 + ((size_t)pair * p.blocks_per_pair + blk) * DVO_STRIDE);
+            block_reduce_terms_buf(acc2, p.partials2 + ((size_t)pair * p.blocks_per_pair + blk) * DVO_STRIDE, tbuf);
+        }
+        if constexpr (WMODE == 5) {
+            __syncthreads();
+            block_reduce_terms_buf<6>(acc3, p.partials2 + ((size_t)pair * p.blocks_per_pair + blk) * DVO_STRIDE + 21, tbuf);
         }
     }
 }
@@ -1795,6 +1813,80 @@ __device__ __forceinline__ void solve6(const double* hu, const double* b, double
     solve6_pinv(hu, b, dmax, x, ws);
 }
 
+// What a perturbation |db_j| <= dbound[j] of the right-hand side can move the solution of H x = b by, component by component:
+// ebound[k] = sum_j |H^-1|_kj dbound[j] (rigorous: the triangle inequality on x = H^-1 b), from the explicit inverse (six unit-vector
+// solves on the LDL^T factors).  Also hdiag[k] = (H^-1)_kk and, when h1 != null, *trace1 = trace(H^-1 H1).  Returns false when H is
+// not safely positive definite.  Only the one-pass Student-t iterations call it (one lane; ~300 float64 operations); out of line so
+// that the common control path does not carry its registers.
+__device__ __noinline__ bool solve6_inverse_bound(const double* hu, const double* dbound, const double* h1 /* 21 packed or null */,
+                                                  double* ebound, double* hdiag, double* trace1)
+{
+    double a[21];
+#pragma unroll
+    for (int q = 0; q < 21; ++q) a[q] = hu[q];
+    double dmax = 0.0;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) dmax = fmax(dmax, fabs(a[lo6(i, i)]));
+    if (!(dmax > 0.0) || !isfinite(dmax)) return false;
+    bool ok = true;
+    double rd[6];
+    const double dmin = 1e-13 * dmax;
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+        double v[6];
+        double d = a[lo6(j, j)];
+#pragma unroll
+        for (int k = 0; k < j; ++k) {
+            v[k] = a[lo6(j, k)] * a[lo6(k, k)];
+            d = fma(-a[lo6(j, k)], v[k], d);
+        }
+        ok = ok && (d > dmin);
+        d = ok ? d : 1.0;
+        a[lo6(j, j)] = d;
+        rd[j] = 1.0 / d;
+#pragma unroll
+        for (int i = j + 1; i < 6; ++i) {
+            double sacc = a[lo6(i, j)];
+#pragma unroll
+            for (int k = 0; k < j; ++k) sacc = fma(-a[lo6(i, k)], v[k], sacc);
+            a[lo6(i, j)] = sacc * rd[j];
+        }
+    }
+    if (!ok) return false;
+    double tr = 0.0;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) ebound[k] = 0.0;
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {                           // column j of H^-1
+        double x[6];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {                       // L z = e_j (z_i = 0 above j)
+            double sacc = (i == j) ? 1.0 : 0.0;
+#pragma unroll
+            for (int k = j; k < i; ++k) sacc = fma(-a[lo6(i, k)], x[k], sacc);
+            x[i] = (i < j) ? 0.0 : sacc;
+        }
+#pragma unroll
+        for (int i = 0; i < 6; ++i) x[i] *= rd[i];
+#pragma unroll
+        for (int i = 5; i >= 0; --i) {                      // L^T x = w
+            double sacc = x[i];
+#pragma unroll
+            for (int k = i + 1; k < 6; ++k) sacc = fma(-a[lo6(k, i)], x[k], sacc);
+            x[i] = sacc;
+        }
+        hdiag[j] = x[j];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) ebound[k] = fma(fabs(x[k]), dbound[j], ebound[k]);
+        if (h1 != nullptr) {
+#pragma unroll
+            for (int k = 0; k < 6; ++k) tr = fma(x[k], h1[(k >= j) ? lo6(k, j) : lo6(j, k)], tr);
+        }
+    }
+    *trace1 = tr;
+    return true;
+}
+
 __global__ void k_init_state(DvoPairState* st, float* T, const float* T_init, int n_pairs, double lambda0,
                              const double* prior_qt)
 {
@@ -1843,6 +1935,7 @@ __global__ void k_init_state(DvoPairState* st, float* T, const float* T_init, in
     s.lam_hist[0] = s.lam_hist[1] = s.lam_hist[2] = 0.0;
     s.lam_n = 0;
     s.pad2 = 0;
+    s.lam_err = 1.0;
     st[i] = s;
     se3_write_T(s.q, s.t, T + (size_t)i * 12);
     (void)lambda0;
@@ -1856,26 +1949,31 @@ hipError_t dvo_launch_init_state(DvoPairState* st, float* T, const float* T_init
 }
 
 // start of a pyramid level: err_prev = FLT_MAX, err_increased_count = 0 (base_robust_dvo.py:158-159)
-__global__ void k_level_begin(DvoPairState* st, int* active, double* wparam, int n_pairs, int weight_mode, double lambda0)
+// one_pass: the level starts with the corrected one-pass Student-t form, whose weights are evaluated under a guessed lambda (wparam):
+// a quarter of the last lambda of the level before (four times the points: lambda = 1 / sum w r^2), or 0 when there is none (the plain
+// moment form).  Any guess is legal - the control step bounds what it costs - a closer one just leaves a smaller remainder.
+__global__ void k_level_begin(DvoPairState* st, int* active, double* wparam, int n_pairs, int weight_mode, double lambda0, int one_pass)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_pairs) return;
     st[i].err_prev = DVO_FLT_MAX;
     st[i].increased = 0;
     st[i].active = 1;
+    const double guess = (st[i].lam_n > 0 && st[i].lam_hist[0] > 0.0) ? 0.25 * st[i].lam_hist[0] : 0.0;
     st[i].lam_n = 0;
+    st[i].lam_err = 1.0;
     active[i] = 1;
     for (int k = 0; k < 4; ++k) st[i].oq[k] = st[i].lq[k];          // old = last_estimated_transform.copy()  (:154)
     for (int k = 0; k < 3; ++k) st[i].ot[k] = st[i].lt[k];
-    if (weight_mode == 1 || weight_mode == 3) wparam[i] = lambda0;                 // t_weighter.py:23
+    if (weight_mode == 1 || weight_mode == 3) wparam[i] = one_pass ? guess : lambda0;   // t_weighter.py:23
     if (weight_mode == 2) wparam[i] = (st[i].lambda > 0.0) ? st[i].lambda : DVO_FLT_MAX;   // no scale yet: w = 1
 }
 
 hipError_t dvo_launch_level_begin(DvoPairState* st, int* active, double* wparam, int n_pairs, int weight_mode,
-                                  double lambda0, hipStream_t s)
+                                  double lambda0, int one_pass, hipStream_t s)
 {
     hipLaunchKernelGGL(k_level_begin, dim3((n_pairs + 63) / 64), dim3(64), 0, s, st, active, wparam, n_pairs,
-                       weight_mode, lambda0);
+                       weight_mode, lambda0, one_pass);
     return hipGetLastError();
 }
 
@@ -1883,18 +1981,33 @@ hipError_t dvo_launch_level_begin(DvoPairState* st, int* active, double* wparam,
 // `rec` is the summed normal-equation record (modified in place when the motion prior is on).
 // P supplies the scalars (tolerance, max_increased, weight_mode, weight_param, inv_sigma, trace*): DvoSolveParams (k_solve:
 // state / T / active / wparam in global memory) or DvoSmallParams (k_gn_small: the same objects held in LDS).
-// Student-t of the reference in ONE pass over the points ("moment form"; weighter/t_weighter.py:21-47 + base_robust_dvo.py:171-188).
+//
+// Student-t of the reference in ONE pass over the points (weighter/t_weighter.py:21-47 + base_robust_dvo.py:171-188).
 // The reference's IRLS restarts every Gauss-Newton iteration from lambda0 = 1/25, takes lambda1 = 1 / S(lambda0), then
 // lambda2 = 1 / S(lambda1) and stops (|lambda2 - lambda1| < 1e-3): because its scale S is a SUM over the image (quirk Q3), lambda1 and
-// lambda2 are ~1e-9..1e-7 and x = lambda r^2 / 5 is tiny for every point, so 6 / (5 + lambda r^2) = 1.2 (1 - x + x^2 - ...):
-//   S(lambda1)  = 1.2 (M1 - x1 M2 + x1^2 M3 - x1^3 M4)          Mk = sum r^(2k): moments of the SAME pass
-//   J^T W J     = 1.2 (H0 - x2 H1),   J^T W r = 1.2 (b0 - x2 b1),   sum w r^2 = 1.2 (M1 - x2 M2 + x2^2 M3)
-// with H0, b0 the unweighted sums and H1 = sum r^2 J J^T, b1 = sum r^2 J r (rec2).  S(lambda0) is summed exactly per point (lambda0 is a
-// constant).  What the expansion drops is second order in x; it is bounded here per iteration (`inexact` counts the iterations whose
-// bound is not met or whose IRLS would not take exactly two passes; the host then repeats the solve with the three-pass form).
-// In: rec = {H0, b0, M1 [27], N [28], S(lambda0) [29]}, rec2 = {H1, b1, M2 [27], M3 [28], M4 [29]}.  Out: rec as a weighted record
-// ([27] = sum w r^2, [29] = sum r^2); returns the bound on the neglected part of J^T W r per component (dbound[6]).
-__device__ __forceinline__ bool student_t_moment_combine(double* rec, const double* rec2, double lambda0, double* dbound, double* lam_out)
+// lambda2 are ~1e-9..1e-7 and x = lambda r^2 / 5 is tiny for every point.  One pass yields
+//   S(lambda0)  summed exactly per point (lambda0 is a constant),
+//   S(lambda1)  = 1.2 (M1 - x1 M2 + x1^2 M3 [- x1^3 M4]),   Mk = sum r^(2k): moments of the SAME pass      => the exact lambda2,
+// and the weighted sums under a GUESSED lambda_g (w_g = 6 / (5 + r^2 lambda_g)), corrected to first order in d = lambda2 - lambda_g
+// with their derivatives, which are sums of the same pass too.  The identity behind it, per point:
+//   w(lambda2) = w_g - (d / 6) r^2 w_g^2 + rho,     rho = (d / 6)^2 r^4 w_g^2 w(lambda2)   (>= 0, exact)
+// "corrected form" (first iterations of a level; lambda_g = 0 - i.e. w_g = 1.2, the plain moment form - at the first level, a
+// quarter of the level before's last lambda at the first iteration of a level, then the last / the linearly extrapolated one):
+//   J^T W J = Hg - (d / 6) H1,   J^T W r = bg - (d / 6) b1,     H1 = sum w_g^2 r^2 J J^T,  b1 = sum w_g^2 r^3 J  (second record)
+// "predicted form" (from the fourth iteration on; lambda_g = the geometric extrapolation of the last three lambdas, good to
+// 1e-4..1e-3 relative): only the right-hand side is corrected (b1: six extra sums), the matrix is kept as it is.
+// What each form drops is bounded per iteration ON THE INCREMENT (gn_control): rho in the right-hand side through Cauchy-Schwarz
+// (dbound), the matrix through eps >= || H^-1/2 dH H^-1/2 ||.  Return value: 0 the form applies; 1 x is too large for the series of
+// S(lambda1) (the pair is solved again with the passes as written, which check the shape of the loop exactly); 2 the series holds
+// and the reference's loop would not take exactly two passes here (solved again by the loop itself).
+//
+// Corrected form.  In: rec = {Hg, bg, M1 [27], N [28], S(lambda0) [29]}, rec2 = {H1, b1, M2 [27], M3 [28], M4 [29]}.  Out: rec as a
+// weighted record under lambda2 ([27] = sum w r^2, [29] = sum r^2).
+//   |db_k| <= sum rho |J_k r| <= 1.2 (d/6)^2 sqrt(sum w_g^2 r^8 . sum w_g^2 r^2 J_k^2) <= 0.04 d^2 sqrt(M4 H1_kk)
+//   dH = sum rho J J^T <= 1.2 (d/6)^2 r2max H1  (positive semi-definite order; r2max = M4^(1/4) >= every r^2)
+//      => eps = eps_fac trace(H^-1 H1),  eps_fac = d^2 r2max / 30   (the caller has H^-1)
+__device__ __forceinline__ int student_t_moment_combine(double* rec, const double* rec2, double lambda0, double lam_g, double* dbound,
+                                                        double* lam_out, double* eps_fac)
 {
     const double S0 = rec[29], M1 = rec[27], M2 = rec2[27], M3 = rec2[28], M4 = rec2[29];
     const double lam1 = 1.0 / S0;
@@ -1904,29 +2017,29 @@ __device__ __forceinline__ bool student_t_moment_combine(double* rec, const doub
     const double lam2 = 1.0 / S1;
     ok = ok && (S1 > 0.0) && isfinite(lam2) && (fabs(lam2 - lam1) < 1e-3);             // the reference stops after the second pass
     const double x2 = lam2 * 0.2;
-    // r^2 <= M4^(1/4): every point's x is below xmax; the series and the first-order weights need xmax << 1
-    const double xmax = fmax(x1, x2) * sqrt(sqrt(M4));
-    ok = ok && (xmax < 1e-2);
+    // r^2 <= M4^(1/4): every point's x is below xmax; the series of S(lambda1) and of sum w r^2 need xmax << 1
+    const double r2max = sqrt(sqrt(M4));
+    const double xmax = fmax(fmax(x1, x2), lam_g * 0.2) * r2max;
+    const bool series = (xmax < 1e-2) && (lam_g >= 0.0);
+    const double d = lam2 - lam_g, c = d * (1.0 / 6.0);
 #pragma unroll
-    for (int q = 0; q < 27; ++q) rec[q] = 1.2 * (rec[q] - x2 * rec2[q]);
+    for (int q = 0; q < 27; ++q) rec[q] = fma(-c, rec2[q], rec[q]);
     rec[27] = 1.2 * (M1 - x2 * (M2 - x2 * M3));
     rec[29] = M1;
-    // neglected part of J^T W r, component k: 1.2 x2^2 |sum r^4 J_k r| <= 1.2 x2^2 sqrt(sum r^8) sqrt(sum r^2 J_k^2) (Cauchy-Schwarz)
     const int dg[6] = {0, 6, 11, 15, 18, 20};
 #pragma unroll
-    for (int k = 0; k < 6; ++k) dbound[k] = 1.2 * x2 * x2 * sqrt(M4 * fmax(rec2[dg[k]], 0.0));
+    for (int k = 0; k < 6; ++k) dbound[k] = 0.04 * d * d * sqrt(M4 * fmax(rec2[dg[k]], 0.0));
+    *eps_fac = d * d * r2max * (1.0 / 30.0);
     *lam_out = lam2;
-    return ok;
+    return series ? (ok ? 0 : 2) : 1;        // (without the series lambda2 is not known well enough to judge the shape: the passes as written do)
 }
 
-// ... and, once three iterations of a level have run, with the weights evaluated per point under a PREDICTED lambda (extrapolated
-// from the last three: lambda moves by < 1 % per Gauss-Newton iteration and settles geometrically), so that no second set
-// of sums is needed: rec = {J^T W J, J^T W r under lambda_p, S(lambda0) [27], N [28], M1 [29], M2 [30], M3 [31]}.  The pass still
-// yields the exact lambda2 (as above, from S(lambda0) and the moments); the weighted sums differ from those under lambda2 by
-// d(J^T W r)_k = 0.24 (lambda_p - lambda2) sum r^3 J_k (1 + O(x)), bounded with Cauchy-Schwarz by 0.24 |lambda_p - lambda2|
-// sqrt(M3 sum J_k^2): measured 6-14 x the true difference on the reference's fixtures (which is 1e-8..4e-7 of the increment).
-// Out: rec as a weighted record under lambda2 ([27] = sum w r^2 from the moments, [29] = sum r^2); returns lambda2.
-__device__ __forceinline__ bool student_t_predicted_combine(double* rec, double lambda0, double lam_p, double* dbound, double* lam_out)
+// Predicted form.  In: rec = {Hp, bp under lam_p, S(lambda0) [27], N [28], M1 [29], M2 [30], M3 [31]}, b1[6] = sum w_p^2 r^3 J.  Out:
+// rec as a weighted record under lambda2 ([27] = sum w r^2 from the moments, [29] = sum r^2).
+//   |db_k| <= sum rho |J_k r| <= 1.2 (d/6)^2 r2max sqrt(sum w_p^2 r^6 . sum w_p^2 J_k^2) <= (d^2 / 30) r2max sqrt(1.728 M3 H_kk)
+//   |dH| <= sum |w(lambda2) - w_p| J J^T <= 0.2 |d| r2max (1 + xmax) H   => eps      (r2max = M3^(1/3) >= every r^2)
+__device__ __forceinline__ int student_t_predicted_combine(double* rec, const double* b1, double lambda0, double lam_p, double* dbound,
+                                                           double* lam_out, double* eps)
 {
     const double S0 = rec[27], M1 = rec[29], M2 = rec[30], M3 = rec[31];
     const double lam1 = 1.0 / S0;
@@ -1939,16 +2052,21 @@ __device__ __forceinline__ bool student_t_predicted_combine(double* rec, double 
     // r^2 <= M3^(1/3) for every point: with xmax < 1 the two series (S(lambda1) above, sum w r^2 below) alternate with decreasing
     // terms, so stopping after the M3 term is off by less than the next one, x^3 M4 <= x^3 M3^(4/3): kept below 1e-6 of the sum
     const double c3 = cbrt(M3);
-    const double xmax = fmax(x1, x2) * c3;
-    ok = ok && (xmax < 0.5) && (xmax * xmax * xmax * c3 <= 1e-6 * M1);
+    const double xmax = fmax(fmax(x1, x2), lam_p * 0.2) * c3;
+    const bool series = (xmax < 0.5) && (xmax * xmax * xmax * c3 <= 1e-6 * M1) && (lam_p >= 0.0);
+    const double d = lam2 - lam_p, c = d * (1.0 / 6.0);
     const int dg[6] = {0, 6, 11, 15, 18, 20};
 #pragma unroll
-    for (int k = 0; k < 6; ++k) dbound[k] = 0.24 * fabs(lam_p - lam2) * sqrt(M3 * fmax(rec[dg[k]], 0.0) * (1.0 / 1.2));
+    for (int k = 0; k < 6; ++k) {
+        dbound[k] = d * d * (1.0 / 30.0) * c3 * sqrt(1.728 * M3 * fmax(rec[dg[k]], 0.0));
+        rec[21 + k] = fma(-c, b1[k], rec[21 + k]);
+    }
+    *eps = 0.2 * fabs(d) * c3 * (1.0 + xmax);
     rec[27] = 1.2 * (M1 - x2 * (M2 - x2 * M3));
     rec[30] = 0.0;
     rec[31] = 0.0;
     *lam_out = lam2;
-    return ok;
+    return series ? (ok ? 0 : 2) : 1;        // (without the series lambda2 is not known well enough to judge the shape: the passes as written do)
 }
 
 // The scalars gn_control reads, for k_gn_small: a copy in LDS filled once per launch.  Read from the kernel arguments they are
@@ -1959,6 +2077,9 @@ struct DvoControlParams {
     double tolerance, weight_param, inv_sigma;
     double* trace;
     int* irls_done;
+    const int* trace_row;
+    int* pair_flags;             // always null here: the persistent kernel repeats an unsafe iteration itself
+    double st_tol;
     int max_increased, weight_mode, trace_stride, trace_cap;
 };
 
@@ -1966,12 +2087,13 @@ template <class P>
 __device__ __forceinline__ void gn_control(const P& p, int phase, int pair, DvoPairState& st, float* T, int* active,
                                            double* wparam, double* rec, double* ws /* [72] LDS workspace */,
                                            const double* rec2 = nullptr, int* inexact = nullptr, double lambda0 = 0.0,
-                                           int predicted = 0, double lam_known = -1.0)
+                                           int predicted = 0, double lam_known = -1.0, const double* b1 = nullptr)
 {
-    // predicted: 1 = the record was weighted under the predicted lambda in *wparam, unsafe iterations are counted in inexact[0..3]
-    // (k_solve; the host repeats the batch); 2 = the same inside k_gn_small: an unsafe iteration sets *inexact = 1 and returns with
-    // the state untouched (the kernel runs the iteration again as written).  lam_known > 0: the lambda the IRLS loop of this
-    // iteration ended on (k_gn_small's exact path), recorded for the prediction.
+    // rec2: the second record of the corrected form (H1, b1, moments), or null; b1: the six sums the predicted form corrects its
+    // right-hand side with (predicted != 0)
+    // predicted: 1 = the record was weighted under the predicted lambda in *wparam (k_solve); unsafe iterations are counted in
+    // inexact[0..3] and their pair is flagged (the host solves it again).  lam_known > 0: the lambda the IRLS loop of this
+    // iteration ended on (k_gn_small), recorded for the guess of the next level's first one-pass iteration.
     if (phase != 0) {
         // Student-t scale pass k (weighter/t_weighter.py:24-32): lambda <- 1 / scale, stop when lambda has settled.
         //   weight_mode 1 (the reference): scale = SUM of the weighted r^2 (quirk Q3), |d lambda| < 1e-3 absolute
@@ -1987,11 +2109,13 @@ __device__ __forceinline__ void gn_control(const P& p, int phase, int pair, DvoP
     }
 
     double dbound[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
-    bool moment_ok = true;
+    const double lam_pred_in = *wparam;     // Student-t: the lambda predicted for this iteration at the end of the one before
+    int form = 0;                           // 0: the one-pass form applies; 1: series not applicable; 2: IRLS not of the two-pass shape
     const bool one_pass = (rec2 != nullptr) || (predicted != 0);
-    double lam2 = 0.0;
-    if (rec2 != nullptr) moment_ok = student_t_moment_combine(rec, rec2, lambda0, dbound, &lam2);
-    else if (predicted) moment_ok = student_t_predicted_combine(rec, lambda0, *wparam, dbound, &lam2);
+    double lam2 = 0.0, eps_fac = 0.0;
+    if (rec2 != nullptr) form = student_t_moment_combine(rec, rec2, lambda0, *wparam, dbound, &lam2, &eps_fac);
+    else if (predicted) form = student_t_predicted_combine(rec, b1, lambda0, *wparam, dbound, &lam2, &eps_fac);
+    const bool moment_ok = (form == 0);
     const double n = rec[28];
     double err = (n > 0.0) ? (double)(float)(rec[27] / n) : __builtin_nan("");      // np.mean(...) float32, :177/:184
     double bneg[6], inc[6];
@@ -2012,27 +2136,48 @@ __device__ __forceinline__ void gn_control(const P& p, int phase, int pair, DvoP
     solve6(rec, bneg, inc, ws);
     asm volatile("" ::: "memory");
     if (one_pass && inexact != nullptr) {
-        // what the one-pass form neglects moves the increment by at most ~dbound_k / H_kk per component (Cauchy-Schwarz bounds,
-        // 1.2-14 x the true difference on the reference's fixtures): keep that inside the 1e-5 parity bound, else count the
-        // iteration (the host repeats the batch with the three-pass form)
-        const int dg[6] = {0, 6, 11, 15, 18, 20};
-        double dmax = 0.0, imax = 0.0;
-        for (int k = 0; k < 6; ++k) { dmax = fmax(dmax, dbound[k] / rec[dg[k]]); imax = fmax(imax, fabs(inc[k])); }
-        const bool bound_ok = dmax <= (predicted ? 8e-6 : 2e-6) * imax;
-        if (predicted == 2) {
-            if (!(moment_ok && bound_ok)) { *inexact = moment_ok ? 1 : 2; return; }    // (also n == 0: dmax is NaN)
-        } else if (n > 0.0) {
+        // What the one-pass form changes, bounded on the increment itself (not on the right-hand side alone):
+        //   inc_true - inc = (H + dH)^-1 (db - dH inc),   |db_k| <= dbound_k (Cauchy-Schwarz bounds of the combine functions),
+        //   || H^-1/2 dH H^-1/2 || <= eps (above)
+        //   => |inc_true - inc|_k <= ( sum_j |H^-1|_kj dbound_j  +  eps sqrt((H^-1)_kk inc^T b) ) / (1 - eps)
+        // (first term: triangle inequality with the explicit inverse; second: |e_k| <= sqrt((H^-1)_kk) ||e||_H and
+        // ||(H + dH)^-1 dH inc||_H <= eps / (1 - eps) ||inc||_H with ||inc||_H^2 = inc^T b).  The iteration is kept when the 2-norm
+        // of that bound is within `tol` of the increment's, half the parity tolerance of 1e-5; else it is run again as written
+        // (inside the launch: k_gn_small; per pair, after the batch: k_solve, see DvoSolveParams::pair_flags).
+        double eb[6], hd[6], tr1 = 0.0;
+        const bool inv_ok = solve6_inverse_bound(rec, dbound, rec2, eb, hd, &tr1);
+        const double eps = (rec2 != nullptr) ? eps_fac * fmax(tr1, 0.0) : eps_fac;
+        double e2 = 0.0, i2 = 0.0, ib = 0.0, eb2 = 0.0;
+        for (int k = 0; k < 6; ++k) ib = fma(inc[k], bneg[k], ib);
+        for (int k = 0; k < 6; ++k) {
+            const double bk = eb[k] + eps * sqrt(fmax(hd[k] * ib, 0.0));
+            e2 = fma(bk, bk, e2);
+            eb2 = fma(eb[k], eb[k], eb2);
+            i2 = fma(inc[k], inc[k], i2);
+        }
+        const bool bound_ok = inv_ok && (eps < 0.5) && (e2 <= (p.st_tol * p.st_tol) * (1.0 - eps) * (1.0 - eps) * i2);
+        rec[30] = (i2 > 0.0) ? sqrt(e2 / i2) / (1.0 - eps) : 0.0;       // (trace / diagnostics: the bound relative to the increment, and eps)
+#ifdef DVO_ST_PROBE_EB
+        rec[31] = (i2 > 0.0) ? sqrt(eb2 / i2) : 0.0;
+#else
+        rec[31] = eps;
+#endif
+        if (n > 0.0) {
             // inexact[0]: iterations that failed; [1]: the IRLS would not take exactly two passes / series not applicable;
             // [2]: bound of the moment form; [3]: bound of the predicted-lambda form
             if (!moment_ok) atomicAdd(inexact + 1, 1);
             else if (!bound_ok) atomicAdd(inexact + (predicted ? 3 : 2), 1);
-            if (!(moment_ok && bound_ok)) atomicAdd(inexact, 1);
+            if (!(moment_ok && bound_ok)) {
+                atomicAdd(inexact, 1);
+                if (p.pair_flags != nullptr) p.pair_flags[pair] |= (form == 2) ? 2 : 1;
+            }
         }
     }
     st.iters += 1;
     st.err_last = err;
     if (p.trace != nullptr && st.iters <= p.trace_cap) {
-        double* tr = p.trace + ((size_t)pair * p.trace_cap + (st.iters - 1)) * p.trace_stride;
+        const int row = (p.trace_row != nullptr) ? p.trace_row[pair] : pair;
+        double* tr = p.trace + ((size_t)row * p.trace_cap + (st.iters - 1)) * p.trace_stride;
         for (int i = 0; i < DVO_STRIDE; ++i) tr[i] = rec[i];
         for (int i = 0; i < 6; ++i) tr[DVO_STRIDE + i] = inc[i];
         for (int i = 0; i < 12; ++i) tr[DVO_STRIDE + 6 + i] = (double)T[i];
@@ -2066,9 +2211,14 @@ __device__ __forceinline__ void gn_control(const P& p, int phase, int pair, DvoP
         if (st.increased > p.max_increased) stop = true;                                // :224
     }
     if (stop) { st.active = 0; *active = 0; }
+    // (control launch after every scale pass, DVO_ST_SOLVE_PHASES: the two passes enqueued did not end the reference's loop)
+    if (p.weight_mode == 1 && p.irls_done != nullptr && p.pair_flags != nullptr && st.pad == 0 && n > 0.0) p.pair_flags[pair] |= 2;
     if (p.weight_mode == 1) { *wparam = 1.0 / 25.0; st.pad = 0; }                       // next iteration restarts IRLS (t_weighter.py:23)
     if (!one_pass && lam_known > 0.0) lam2 = lam_known;
     if (one_pass || lam_known > 0.0) {
+        // how good the prediction of THIS iteration's lambda was (*wparam still holds it when at least two lambdas of this level
+        // were known when it was made): the persistent kernel tries the predicted form only after a prediction within 2e-4
+        st.lam_err = (st.lam_n >= 2 && lam2 > 0.0) ? fabs(lam_pred_in - lam2) / lam2 : 1.0;
         // lambda of the next iteration's weights (the reduction weighted with a predicted lambda reads it from wparam)
         // (lambda settles geometrically with the pose: the next step of the sequence is the last step times the ratio of the last
         // two, clamped to [0, 1]; on the reference's fixtures that predicts lambda to 6e-5..5e-4 relative, ten times better than a
@@ -2106,10 +2256,9 @@ __device__ __forceinline__ void gn_control(const P& p, int phase, int pair, DvoP
 // one on every iteration.  As a function it has no enclosing loop: the literals are built where they are used; what its ~165 live
 // registers cost under the kernel's 128-register cap is spilled inside its own frame, by one lane.
 __device__ __noinline__ void gn_control_small(const DvoControlParams* ctl, int pair, DvoPairState* st, float* T, int* active,
-                                              double* wparam, double* rec, double* ws, int* redo, double lambda0, int predicted,
-                                              double lam_known)
+                                              double* wparam, double* rec, double* ws, double lambda0, double lam_known)
 {
-    gn_control(*ctl, 0, pair, *st, T, active, wparam, rec, ws, nullptr, redo, lambda0, predicted, lam_known);
+    gn_control(*ctl, 0, pair, *st, T, active, wparam, rec, ws, nullptr, nullptr, lambda0, 0, lam_known);
 }
 
 // rec[0..31] (LDS) = the pair's per-workgroup partials summed by one wave in sum_partials_block's order (see k_solve)
@@ -2158,12 +2307,35 @@ __global__ __launch_bounds__(64) void k_solve(const DvoSolveParams p)
     __shared__ double rec[DVO_STRIDE];
     __shared__ double rec2[DVO_STRIDE];
     __shared__ double tmp[8][DVO_STRIDE];
-    const bool moments = (p.partials2 != nullptr) && (p.phase == 0) && !p.predicted;
+    // the one-pass forms leave a second record: the corrected form all of it, the predicted form b1 in its slots 21..26 only
+    const bool second = (p.partials2 != nullptr) && (p.phase == 0);
+    const bool moments = second && !p.predicted;
     solve_sum_partials(p.partials + (size_t)pair * p.blocks_per_pair * DVO_STRIDE, p.blocks_per_pair, rec, tmp);
-    if (moments) solve_sum_partials(p.partials2 + (size_t)pair * p.blocks_per_pair * DVO_STRIDE, p.blocks_per_pair, rec2, tmp);
+    if (second) solve_sum_partials(p.partials2 + (size_t)pair * p.blocks_per_pair * DVO_STRIDE, p.blocks_per_pair, rec2, tmp);
+    if (p.scale1 != nullptr && p.phase == 0 && p.pair_flags != nullptr) {
+        // Passes as written without a control launch between them (two scale passes, then the weighted pass): that IS the
+        // reference's loop (weighter/t_weighter.py:24-32) when its first pass does not converge and its second does, or when the
+        // first converges (student_t_lambda keeps lambda1 then).  Any other shape - a third pass - is flagged: the pair is solved
+        // again by the persistent kernel, which runs the loop itself.  Sums in student_t_lambda's order, so the same lambdas.
+        __shared__ double sg[16];
+        if (threadIdx.x < 16) {
+            const double* x = ((threadIdx.x < 8) ? p.scale1 : p.scale2) + (size_t)pair * p.blocks_per_pair;
+            double s = 0.0;
+            for (int b = threadIdx.x & 7; b < p.blocks_per_pair; b += 8) s += x[b];
+            sg[threadIdx.x] = s;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            double s1 = 0.0, s2 = 0.0;
+            for (int k = 0; k < 8; ++k) s1 += sg[k];
+            for (int k = 0; k < 8; ++k) s2 += sg[8 + k];
+            const double lam1 = 1.0 / s1, lamb2 = 1.0 / s2;
+            if (!(fabs(lam1 - p.lambda0) < 1e-3) && !(fabs(lamb2 - lam1) < 1e-3) && rec[28] > 0.0) p.pair_flags[pair] |= 2;
+        }
+    }
     if (threadIdx.x != 0) return;
     gn_control(p, p.phase, pair, p.state[pair], p.T + (size_t)pair * 12, p.active + pair, p.wparam + pair, rec, &tmp[0][0],
-               moments ? rec2 : nullptr, p.inexact, p.lambda0, (p.phase == 0) ? p.predicted : 0);
+               moments ? rec2 : nullptr, p.inexact, p.lambda0, (p.phase == 0) ? p.predicted : 0, -1.0, rec2 + 21);
 }
 
 hipError_t dvo_launch_solve(const DvoSolveParams& p, hipStream_t s)
@@ -2192,7 +2364,7 @@ hipError_t dvo_launch_solve(const DvoSolveParams& p, hipStream_t s)
 template <int NT>
 __device__ __forceinline__ void wave_reduce_terms(const float* acc, float* wbuf /* [8][65] */, double* out)
 {
-    static_assert(NT == DVO_NACC || NT == DVO_STRIDE, "30 sums, or 32 with the Student-t moments");
+    static_assert(NT == DVO_NACC, "the 30 sums of a normal-equation record");
     const int lane = threadIdx.x & 63;
     const int term = lane & 7, seg = lane >> 3;
 #pragma unroll
@@ -2214,7 +2386,7 @@ __device__ __forceinline__ void wave_reduce_terms(const float* acc, float* wbuf 
         sgm += __shfl_xor(sgm, 32, 64);
         if (seg == 0 && c * 8 + term < NT) out[c * 8 + term] = sgm;
     }
-    if (lane >= NT && lane < DVO_STRIDE) out[lane] = 0.0;
+    if (NT < DVO_STRIDE && lane >= NT && lane < DVO_STRIDE) out[lane] = 0.0;
 }
 
 // ONE kernel for the three launched workgroup sizes (256 / 512 / 1024 threads; blockDim.x is read at run time): all of them are
@@ -2229,7 +2401,6 @@ __device__ __forceinline__ void gn_small_body(const DvoSmallParams& p)
     __shared__ DvoPairState st;
     __shared__ float T_sh[12];
     __shared__ int active_sh;
-    __shared__ int redo_sh;                 // Student-t: the one-pass form of this iteration was not safe, run it again as written
     __shared__ DvoControlParams ctl;
     __shared__ double wpar_sh;
     __shared__ double rec_sh[DVO_STRIDE];
@@ -2244,7 +2415,7 @@ __device__ __forceinline__ void gn_small_body(const DvoSmallParams& p)
     if (tid == 0) {
         st = p.state[pair]; active_sh = 1; wpar_sh = p.wparam[pair];
         ctl.tolerance = p.tolerance; ctl.weight_param = p.weight_param; ctl.inv_sigma = p.inv_sigma;
-        ctl.trace = p.trace; ctl.irls_done = nullptr;
+        ctl.trace = p.trace; ctl.irls_done = nullptr; ctl.trace_row = p.trace_row; ctl.pair_flags = nullptr; ctl.st_tol = 0.0;
         ctl.max_increased = p.max_increased; ctl.weight_mode = p.weight_mode;
         ctl.trace_stride = p.trace_stride; ctl.trace_cap = p.trace_cap;
     }
@@ -2285,6 +2456,7 @@ __device__ __forceinline__ void gn_small_body(const DvoSmallParams& p)
             st.increased = 0;
             st.active = 1;
             st.lam_n = 0;
+            st.lam_err = 1.0;
             active_sh = 1;
             for (int k = 0; k < 4; ++k) st.oq[k] = st.lq[k];
             for (int k = 0; k < 3; ++k) st.ot[k] = st.lt[k];
@@ -2300,19 +2472,10 @@ __device__ __forceinline__ void gn_small_body(const DvoSmallParams& p)
             for (int i = 0; i < 12; ++i) T[i] = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(T_sh[i])));
             float wpar = 0.0f;
             if constexpr (WMODE == 2) wpar = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint((float)wpar_sh)));
-            // Student-t of the reference, from the fourth iteration of a level on: ONE pass over the records with the weights under
-            // the lambda predicted from the last three (student_t_predicted_combine: the pass still yields the exact lambda; the
-            // control step bounds what the prediction costs and, if that is not inside the parity bound, leaves the state alone and
-            // the iteration runs again below as the reference writes it).  Workgroup-uniform: st is in LDS, written before a barrier.
-            bool pred = false;
-            // (from 160 x 120 on: over the ~4 k records of an 80 x 60 level the bound is met by one iteration in seven)
-            if constexpr (WMODE == 1) pred = (p.st_one_pass != 0) && (st.lam_n >= 3) && (g.npix >= 160 * 120);
             double lam_exact = -1.0;
-            for (int attempt = 0; attempt < 2; ++attempt) {
+            {
                 if constexpr (WMODE == 1) {
-                    if (pred) {
-                        wpar = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint((float)wpar_sh)));
-                    } else {
+                    {
                         // TDistributionWeighter.weight (weighter/t_weighter.py:21-34): lambda <- 1 / scale(lambda) until |d lambda| < 1e-3
                         // student_t_mean (weight_mode 3, "proper"): scale = mean, relative tolerance, at most 4 passes, warm-started from the
                         // previous iteration's lambda; otherwise the reference's loop (sum, |d lambda| < 1e-3, at most 50 passes, from 1/25)
@@ -2384,8 +2547,7 @@ __device__ __forceinline__ void gn_small_body(const DvoSmallParams& p)
                     }
                 }
 
-                constexpr int NT = (WMODE == 1) ? DVO_STRIDE : DVO_NACC;     // Student-t: + the moments sum r^4, sum r^6 of the one-pass form
-                const float lam0f = (float)p.lambda0;
+                constexpr int NT = DVO_NACC;
                 float acc[NT];
                 // (an opaque zero: from the literal the compiler keeps a block of NT zeroed registers alive through the whole
                 // iteration loop to copy from, and stores / reloads it around the control call)
@@ -2429,16 +2591,7 @@ __device__ __forceinline__ void gn_small_body(const DvoSmallParams& p)
                                 for (int b = a; b < 6; ++b) { acc[q] = fmaf(wj[a], o.J[b], acc[q]); ++q; }
 #pragma unroll
                             for (int k = 0; k < 6; ++k) acc[21 + k] = fmaf(wj[k], r, acc[21 + k]);
-                            if (WMODE == 1 && pred) {
-                                // (as k_reduce's predicted-lambda form) [27]: the first scale pass under the constant lambda0, exact per
-                                // point; [30], [31]: the moments from which the control step rebuilds the second pass
-                                acc[27] += r2 * (6.0f * fast_rcp(fmaf(r2, lam0f, 5.0f)));
-                                const float r4 = r2 * r2;
-                                acc[NT - 2] += r4;
-                                acc[NT - 1] = fmaf(r4, r2, acc[NT - 1]);
-                            } else {
-                                acc[27] = fmaf((WMODE == 0) ? r : wt * r, r, acc[27]);
-                            }
+                            acc[27] = fmaf((WMODE == 0) ? r : wt * r, r, acc[27]);
                             acc[28] += 1.0f;
                             if (WMODE != 0) acc[29] += r2;
                         }
@@ -2458,21 +2611,13 @@ __device__ __forceinline__ void gn_small_body(const DvoSmallParams& p)
                 stamp(2);
                 if (tid == 0) {
                     __builtin_amdgcn_s_setprio(3);          // the one-lane control chain goes first on its SIMD (see k_solve)
-                    redo_sh = 0;
-                    const double lam_known = (WMODE == 1 && !pred && p.st_one_pass != 0) ? lam_exact : -1.0;
-                    gn_control_small(&ctl, pair, &st, T_sh, &active_sh, &wpar_sh, rec_sh, &wsum[0][0], (WMODE == 1) ? &redo_sh : nullptr,
-                                     p.lambda0, (WMODE == 1 && pred) ? 2 : 0, lam_known);
-                    if (WMODE == 1 && p.st_counts != nullptr && pred) {
-                        atomicAdd(p.st_counts + (redo_sh ? 1 : 0), 1);
-                        if (redo_sh == 2) atomicAdd(p.st_counts + 2, 1);
-                        if (redo_sh && li == 0) atomicAdd(p.st_counts + 3, 1);
-                    }
+                    // (lam_exact: the lambda this iteration's IRLS loop ended on - the control step keeps the last ones of the level, from
+                    // which the first per-iteration level above takes the guess its one-pass form starts from, see k_level_begin)
+                    gn_control_small(&ctl, pair, &st, T_sh, &active_sh, &wpar_sh, rec_sh, &wsum[0][0], p.lambda0, lam_exact);
                     __builtin_amdgcn_s_setprio(0);
                 }
                 __syncthreads();
                 stamp(3);
-                if (!(WMODE == 1 && pred && redo_sh != 0)) break;          // workgroup-uniform
-                pred = false;
             }
         }
         __syncthreads();

@@ -81,7 +81,7 @@ SIGNATURES = {
     "dvo_comm_last_error": (C.c_char_p, []),
     "dvo_trace_enable": (C.c_int, [_ctx, C.c_int]),
     "dvo_student_t_fallbacks": (C.c_int, [_ctx, _c_i64_p]),
-    "dvo_student_t_small_level_counts": (C.c_int, [_ctx, _c_i64_p, _c_i64_p]),
+    "dvo_student_t_fallback_pairs": (C.c_int, [_ctx, _c_i64_p]),
     "dvo_trace_read": (C.c_int, [_ctx, C.c_int, C.c_void_p]),
     "dvo_profile_enable": (C.c_int, [_ctx, C.c_int]),
     "dvo_profile_read": (C.c_int, [_ctx, _c_i64_p, _c_double_p, C.c_int]),
@@ -451,11 +451,11 @@ class HipContext:
         self._check(self._lib.dvo_student_t_fallbacks(self._h, C.byref(n)))
         return int(n.value)
 
-    def student_t_small_level_counts(self) -> tuple:
-        """(kept, redone): iterations of the persistent levels the reference's Student-t ran in one pass, and those run again as written."""
-        kept, redone = C.c_int64(), C.c_int64()
-        self._check(self._lib.dvo_student_t_small_level_counts(self._h, C.byref(kept), C.byref(redone)))
-        return int(kept.value), int(redone.value)
+    def student_t_fallback_pairs(self) -> int:
+        """Pairs this context solved again because a one-pass Student-t iteration could not be bounded or the IRLS had another shape."""
+        n = C.c_int64()
+        self._check(self._lib.dvo_student_t_fallback_pairs(self._h, C.byref(n)))
+        return int(n.value)
 
     def small_stamps(self, n_pairs: int, reset: bool = True) -> np.ndarray:
         """(n_pairs, 8) uint64 phase clocks of the persistent small-level kernel (experiment build of the library, -DDVO_EXPERIMENTS,

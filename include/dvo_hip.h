@@ -30,6 +30,18 @@
  *   [0..20]  upper triangle of H = J^T W J, row-major (H00 H01 .. H05 H11 .. H55)
  *   [21..26] J^T W r      (the caller negates: b = -J^T W r, base_robust_dvo.py:188)
  *   [27]     sum w r^2    [28] number of valid pixels N    [29] sum r^2    [30..31] reserved (0)
+ *
+ * Environment (every variable is read ONCE, at dvo_create; a captured solve graph bakes the values in):
+ *   DVO_GRAPH=0            plain launches instead of hipGraph replay of the device-side solve
+ *   DVO_ST_EXACT           DVO_WEIGHT_STUDENT_T: no one-pass forms anywhere (passes as written; see dvo_solve_batch)
+ *   DVO_ST_SOLVE_PHASES    ... passes as written with a control launch after every scale pass (the original flow)
+ *   DVO_NO_RCACHE          ... the second scale pass recomputes the residuals instead of reading the first pass's
+ *   DVO_INGEST_UNFUSED     separate ingest kernels at every level (the path odd image sizes take anyway)
+ *   DVO_SMALL_MAX_PIX=n    pyramid levels of at most n pixels run in the persistent per-pair kernel (default 19200; 0: none)
+ *   DVO_SMALL_THREADS=n    workgroup size of that kernel, 256 / 512 / 1024 (default: chosen from the batch size)
+ *   DVO_RCCL_LIB=path      RCCL library dvo_comm_create loads (default librccl.so)
+ * These are tested configuration switches.  Tuning and diagnostic knobs (DVO_EXP_TAPS, DVO_SMALL_STAMPS, DVO_TARGET_BLOCKS, ...)
+ * exist only in experiment builds of the library (-DDVO_EXPERIMENTS, bottom of this file).
  */
 #ifndef DVO_HIP_H
 #define DVO_HIP_H
@@ -188,18 +200,26 @@ int dvo_residuals_jacobian(dvo_ctx* ctx, int level, int prev_slot, int cur_slot,
  * base_robust_dvo.py:137-236): no host round trip; stop rules evaluated per pair on the device.  Pyramid levels of at most
  * 160 x 120 pixels run in one persistent launch (a workgroup per pair does all their iterations); finer levels take one
  * reduction launch and one control launch per iteration.
- * Student-t IRLS (weighter/t_weighter.py:21-34): on the persistent levels the reference's loop as written (until
- * |d lambda| < 1e-3, at most 50 passes) — for DVO_WEIGHT_STUDENT_T from the fourth iteration of a level on in ONE pass with
- * the weights under a lambda predicted from the last three, whenever the control step can bound what the prediction costs
- * inside the parity tolerance; an iteration where it cannot runs again, inside the launch, as written.  On the finer levels DVO_WEIGHT_STUDENT_T_MEAN runs its at most four passes, and
- * DVO_WEIGHT_STUDENT_T the TWO scale passes the reference's loop takes whenever the summed scale exceeds 1000 (any image with
- * more than a few hundred non-zero residuals: lambda is then below 1e-3 after the first pass, so the second difference is
- * too) — at levels of 320 x 240 and more evaluated in ONE pass over the points: the scale sum of the second pass and the
- * weighted normal equations are series in lambda r^2 / 5 (below ~1e-4 there, because the reference's scale is a SUM over
- * the image) whose terms are moments of the same pass, kept to the order that leaves J^T W J, J^T W r exact to ~1e-9; every
- * iteration checks a bound on what the series drops, and a batch in which the bound fails (or the loop would not take
- * exactly two passes) is solved again with the passes as written before dvo_solve_batch / dvo_solve_batch_fetch return.
- * The environment variable DVO_ST_EXACT (read at dvo_create) forces the passes as written everywhere.
+ * Student-t IRLS (weighter/t_weighter.py:21-34), DVO_WEIGHT_STUDENT_T (the reference's weighter, summing quirk included):
+ *   - persistent levels: the reference's loop as written (until |d lambda| < 1e-3, at most 50 passes);
+ *   - finer levels (one launch per iteration): the TWO scale passes the reference's loop takes whenever the summed scale exceeds
+ *     1000 (any image with more than a few hundred non-zero residuals: lambda is then below 1e-3 after the first pass, so the second
+ *     difference is too) - for DVO_VARIANT_V1 at levels of 320 x 240 and more evaluated in ONE pass over the points: the scale sum of
+ *     the second pass and the weighted normal equations are series in lambda r^2 / 5 (below ~1e-4 there, because the reference's
+ *     scale is a SUM over the image) whose terms are moments of the same pass; every iteration bounds, on the increment itself
+ *     (explicit H^-1, right-hand side and matrix perturbation), what the form drops, at half the parity tolerance of 1e-5;
+ *   - FALLBACK, PER PAIR, before dvo_solve_batch / dvo_solve_batch_fetch return: a pair with an iteration whose bound was not met is
+ *     solved again with the passes as written; a pair whose IRLS does not have that two-pass shape at some iteration of a finer level
+ *     (detected by the one-pass forms and by the passes as written alike) is solved again with EVERY level in the persistent kernel,
+ *     i.e. by the reference's loop itself.  Only the flagged pairs are solved again (one compacted batch per form); the other pairs
+ *     of the batch keep their results.  dvo_student_t_fallbacks / dvo_student_t_fallback_pairs count them.
+ *   The environment variable DVO_ST_EXACT (read at dvo_create) switches the one-pass forms off everywhere (passes as written, shape
+ *   fallback as above).  DVO_VARIANT_V3 keeps per-iteration launches with two scale passes at every level and has no fallback.
+ *   DVO_WEIGHT_STUDENT_T_MEAN (build-defined) runs at most four passes at the finer levels.
+ * RULE for the split enqueue / fetch form with DVO_WEIGHT_STUDENT_T: the fallback reads the FRAMES at fetch time, so the slots of an
+ * enqueued solve must not be uploaded again before its fetch (checked: DVO_ERR_BAD_STATE from the fetch if a pair that needs the
+ * fallback lost its frames; pairs that do not need it are unaffected).  T_init, the prior and the level schedule are copied at
+ * enqueue and may change freely.
  *   T_init  n_pairs x 12 or NULL (identity)          T_out   n_pairs x 12
  *   xi_out  n_pairs x 6 float64 log of the estimate (may be NULL)
  *   iters_out n_pairs (total GN iterations run, may be NULL)   err_out n_pairs (last accepted error, may be NULL) */
@@ -212,11 +232,10 @@ int dvo_solve_batch_enqueue(dvo_ctx* ctx, int n_pairs, const int* prev_slot, con
                             int max_iterations, double tolerance, int max_increased_steps_allowed, int variant,
                             int weight_mode, double weight_param, const float* T_init);
 int dvo_solve_batch_fetch(dvo_ctx* ctx, int n_pairs, float* T_out, double* xi_out, int* iters_out, double* err_out);
-/* Diagnostic: number of DVO_WEIGHT_STUDENT_T solves this ctx had to repeat with the three-pass form (see above). */
+/* Diagnostic: number of fetched DVO_WEIGHT_STUDENT_T solves in which at least one pair had to be solved again (see above) ... */
 int dvo_student_t_fallbacks(const dvo_ctx* ctx, int64_t* count);
-/* Diagnostic: over every DVO_WEIGHT_STUDENT_T solve fetched so far, the iterations of the persistent levels that ran in one pass
- * (*kept) and those that were run again as written because the bound was not met (*redone). */
-int dvo_student_t_small_level_counts(const dvo_ctx* ctx, int64_t* kept, int64_t* redone);
+/* ... and the number of pairs solved again over all of them. */
+int dvo_student_t_fallback_pairs(const dvo_ctx* ctx, int64_t* pairs);
 
 /* Motion prior of the reference (sigma, base_robust_dvo.py:69-71,:154,:190-194,:217-218) for subsequent
  * dvo_solve_batch calls: H += I/sigma, b += (I/sigma) log(old), err += 0.5 sigma |log(old)|, old <- inc^-1 old, with

@@ -367,6 +367,43 @@ def test_device_solve_student_t_and_v2(hip, golden_dir):
     np.testing.assert_allclose(res["xi"][0], ga["final_xi"], rtol=0, atol=1e-6)
 
 
+def test_device_solve_student_t_one_pass_iterations_vs_reference_run(hip, frames, pyramids, golden_dir):
+    """The DEFAULT Student-t solve (one pass per iteration at 640x480 and 320x240: corrected / predicted-lambda forms; the reference's
+    loop as written inside the persistent kernel at 160x120 and 80x60) ITERATION BY ITERATION against the reference run of
+    use_weighter=True (weighted_l4.npz: base_robust_dvo.py:171-188 with weighter/t_weighter.py:21-47): every traced increment
+    against the run's float64 increment (free-running, absolute) and, teacher-forced at the pose the device evaluated, against
+    the oracle's weighter loop at the north-star tolerance of 1e-5 relative.  No pair is solved again, and every one-pass
+    iteration's own bound (trace slot 30) is inside the 5e-6 it is kept under."""
+    ctx, cabi = hip
+    gw = np.load(golden_dir / "weighted_l4.npz")
+    n_it = len(gw["level"])
+    fb0 = ctx.student_t_fallback_pairs()
+    ctx.trace_enable(n_it)
+    res = ctx.solve_batch([0], [1], levels=4, max_iterations=10, weight_mode=cabi.WEIGHT_STUDENT_T)
+    tr = ctx.trace_read(1)
+    ctx.trace_enable(0)
+    assert res["iters"][0] == n_it
+    assert ctx.student_t_fallback_pairs() == fb0
+    worst_rel, worst_bound = 0.0, 0.0
+    for j in range(n_it):
+        lvl = int(gw["level"][j])
+        assert int(round(tr[0, j, 28])) == int(gw["n"][j])
+        assert np.abs(tr[0, j, 32:38] - gw["inc64"][j]).max() < 5e-8
+        np.testing.assert_allclose(tr[0, j, 27], gw["sum_wr2"][j], rtol=1e-5)         # (free-running; feeds a float32 mean)
+        T = np.eye(4, dtype=np.float32)
+        T[:3, :] = tr[0, j, 38:50].reshape(3, 4).astype(np.float32)
+        r, J, _, _ = O.residuals_and_jacobian(_level(frames, pyramids, 0, lvl), T)
+        w, _ = O.student_t_weights(r)
+        Ho, bo, so, no = O.normal_equations(r, J, w)
+        rel = _rel(tr[0, j, 32:38], O.solve_increment(Ho, bo))
+        worst_rel = max(worst_rel, rel)
+        assert rel < 1e-5, (j, lvl, rel)
+        if lvl <= 1:                                              # one-pass forms: the iteration's own bound, relative to its increment
+            assert 0.0 < tr[0, j, 30] <= 5e-6, (j, lvl, tr[0, j, 30])
+            worst_bound = max(worst_bound, tr[0, j, 30])
+    print("one-pass Student-t vs oracle, teacher-forced: worst relative increment error %.2e; worst kept bound %.2e" % (worst_rel, worst_bound))
+
+
 @pytest.mark.parametrize("solver", ["host", "device"])
 def test_motion_prior_sigma_vs_reference_run(frames, golden_dir, solver):
     """sigma prior (base_robust_dvo.py:190-194,:217-218) through step(): iteration counts and poses of the

@@ -80,6 +80,7 @@ def test_timeout_terminates_every_rank_and_names_the_stuck_ones(tmp_path):
         "if os.environ['RANK'] == '0':\n"
         "    launch.mark_rank('started'); launch.mark_rank('done'); sys.exit(0)\n"
         "launch.mark_rank('started')\n"
+        "launch.phase('waiting for a peer')\n"
         "time.sleep(600)\n" % str(pidfile))
     code = ("import sys; sys.path.insert(0, %r)\n"
             "from dvo_amd import launch\n"
@@ -91,6 +92,7 @@ def test_timeout_terminates_every_rank_and_names_the_stuck_ones(tmp_path):
     out = _run_driver(code, timeout=120)
     assert out.returncode == 7, out.stdout[-2000:] + out.stderr[-2000:]
     assert "LAUNCH_ERROR" in out.stdout and "did not finish: [1]" in out.stdout, out.stdout
+    assert "rank 1 after 'waiting for a peer'" in out.stdout, out.stdout            # the last phase the stuck rank reported
     import time
     time.sleep(1.0)
     pids = [int(x) for x in pidfile.read_text().split()]
@@ -107,9 +109,65 @@ def test_timeout_terminates_every_rank_and_names_the_stuck_ones(tmp_path):
         assert not alive, "rank process %d survived the timeout" % pid
 
 
-def test_default_timeout_is_finite(monkeypatch):
+def _alive(pid):
+    try:
+        os.kill(pid, 0)
+        state = Path("/proc/%d/status" % pid).read_text().split("State:")[1].split()[0]
+        return state not in ("Z", "X")
+    except (ProcessLookupError, FileNotFoundError):
+        return False
+
+
+@pytest.mark.parametrize("sig", ["SIGTERM", "SIGKILL"])
+def test_a_signalled_driver_takes_its_ranks_with_it(tmp_path, sig):
+    """The ranks live in their own session (so that the launcher can kill the whole group), which means a signal to the DRIVER's
+    group - GNU timeout, a harness' killpg, a closed terminal - does not reach them by itself.  SIGTERM: the driver's handler
+    kills the group.  SIGKILL (no handler can run): the elastic agent dies with the driver (PR_SET_PDEATHSIG) and every rank with
+    the agent.  Either way no rank survives with a GPU still held."""
+    import signal
+    import time
+    pidfile = tmp_path / "pids.txt"
+    stub = tmp_path / "sleepy_worker.py"
+    stub.write_text(
+        "import os, sys, time\n"
+        "sys.path.insert(0, os.environ['DVO_PKG_DIR'])\n"
+        "from dvo_amd import launch\n"
+        "launch.mark_rank('started')\n"
+        "open(%r, 'a').write('%%d\\n' %% os.getpid())\n"
+        "time.sleep(600)\n" % str(pidfile))
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "from dvo_amd import launch\n"
+            "sys.exit(launch.launch_ranks(2, %r, [], need_devices=False, timeout=300))\n" % (str(PKG), str(stub)))
+    env = dict(os.environ, DVO_PKG_DIR=str(PKG), OMP_NUM_THREADS="1")
+    env.pop("WORLD_SIZE", None)
+    env.pop("RANK", None)
+    drv = subprocess.Popen([sys.executable, "-c", code], env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    try:
+        t0 = time.time()
+        while time.time() - t0 < 120 and (not pidfile.exists() or len(pidfile.read_text().split()) < 2):
+            time.sleep(0.5)
+        pids = [int(x) for x in pidfile.read_text().split()]
+        assert len(pids) == 2 and all(_alive(p) for p in pids)
+        drv.send_signal(getattr(signal, sig))
+        rc = drv.wait(timeout=60)
+        assert rc != 0
+        t0 = time.time()
+        while time.time() - t0 < 30 and any(_alive(p) for p in pids):
+            time.sleep(0.5)
+        assert not any(_alive(p) for p in pids), "a rank survived its driver's %s" % sig
+    finally:
+        if drv.poll() is None:
+            drv.kill()
+        for p in (pidfile.read_text().split() if pidfile.exists() else []):
+            try:
+                os.kill(int(p), signal.SIGKILL)
+            except (ProcessLookupError, PermissionError):
+                pass
+
+
+def test_default_timeout_is_below_the_drivers_limit(monkeypatch):
     monkeypatch.delenv("DVO_LAUNCH_TIMEOUT", raising=False)
-    assert 0 < launch.default_timeout() <= 3600
+    assert 0 < launch.default_timeout() <= 450           # the driver gives a bench run 600 s: the launcher must speak first
     monkeypatch.setenv("DVO_LAUNCH_TIMEOUT", "42")
     assert launch.default_timeout() == 42.0
     assert launch.pg_timeout().total_seconds() > 0
