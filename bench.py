@@ -13,7 +13,11 @@ the per-pair pose records are all-gathered over RCCL inside the timed region.
 
 The JSON line also carries
   roofline     — the dominant kernel (level-0 k_reduce): algorithmic bytes of SURVEY 8d (2P + 10V per pair
-                 per launch, with the measured V) / its average duration from HIP events on its own stream
+                 per launch, with the measured V) / its average duration from HIP events on its own stream;
+                 roofline.whole_step: the same figure for the whole job (SURVEY 8d bytes per frame pair x `value`);
+                 roofline.valu_issue: what actually bounds that kernel - its instruction count (static, from the library that
+                 was built; dynamic, the committed PMC reading) x the cost of a wave-instruction measured in this run by
+                 dvo_debug_valu_rate, beside the measured launch time
   cpu_baseline — the NumPy oracle (a port of the reference CPU path) timed on this host on a bounded sample
 and, at N = 1 on the default workload, outside the `value` region (BASELINE.json north_star's report):
   config3             — configs[2]: 1280x960, 5 levels, Huber: frame-pairs/s and its own level-0 roofline object
@@ -277,7 +281,8 @@ def leg_pcie(st, gray, depth, B, W, H, L, iterations, device, steps):
 
 def leg_config3(device, iterations, streams, steps, seed=1234):
     """BASELINE.json configs[2]: synthetic 1280x960 RGB-D stream, 5-level pyramid, Huber weighting, 1 GPU.  The largest batch of
-    512 / 256 / 128 pairs that fits; 129 rendered frames played forwards and backwards (every pair is two consecutive renders)."""
+    1024 / 512 / 256 / 128 pairs that fits (1024 pairs in 4 streams = 256 pairs per launch, the size from which a launch reaches its
+    rate; 1029 frames are ~30 GB of the 288); 129 rendered frames played forwards and backwards (every pair is two consecutive renders)."""
     import numpy as np
     import torch
     from dvo_amd import synthetic
@@ -286,7 +291,7 @@ def leg_config3(device, iterations, streams, steps, seed=1234):
     n_render = 129
     st = synthetic.make_stream(n_render, W, H, seed=seed, device="cuda", as_torch=True)
     last_err = None
-    for B in (512, 256, 128):
+    for B in (1024, 512, 256, 128):
         al = None
         try:
             idx = np.arange(B + 1) % (2 * (n_render - 1))
@@ -328,6 +333,21 @@ def leg_config3(device, iterations, streams, steps, seed=1234):
     return {"error": last_err}
 
 
+def leg_sequence_png(device):
+    """SURVEY 8(f) f2 where it binds: a TUM-layout dataset of PNG files on disk (480 frames listed over 48 distinct renders) through
+    the sequence front end - PNG decode in a thread pool into page-locked windows, batched colour upload + ingest, device solve -
+    with 8 and 16 decoder threads, and the same windows fed from memory (tools/exp_sequence_png.py; the reference harness decodes
+    the whole sequence into RAM first and times step() on decoded frames, src/test_dvo.py:180-191, :305-309).  Bounded to a few
+    seconds; the full sweep is profiles/r04_sequence_png.txt."""
+    sys.path.insert(0, str(ROOT / "tools"))
+    import exp_sequence_png
+    t0 = time.perf_counter()
+    out = exp_sequence_png.measure(n_frames=480, n_distinct=48, threads=(8, 16), window=96, streams=2, device=device, colour=True,
+                                   decode_only=False, from_memory=True)
+    out["leg_seconds"] = time.perf_counter() - t0
+    return out
+
+
 def fixture_ate(device):
     """"ATE vs ref" part of the metric on the only real TUM data in the repo: the reference's 10-frame fr1/xyz
     excerpt (tests/golden/frames.npz) through the HIP path, next to the ATE of the reference run's own trajectory
@@ -348,16 +368,150 @@ def fixture_ate(device):
             "reference_ate_rmse_m": absolute_trajectory_error(ref["pose_T"].astype(np.float64), f["gt_T"])}
 
 
+class _HipBackend:
+    """What main() needs from the machine: the real thing.  A CPU rehearsal of the distributed branch swaps in tests/bench_stub.py
+    through DVO_BENCH_STUB (a stand-in aligner on gloo; no GPU, no kernels - it exists so that the N > 1 code of THIS file runs
+    somewhere before an 8-GPU node shows up)."""
+    name = "hip"
+    device = "cuda"
+    dist_backend = "nccl"
+
+    def check(self, local_rank, rank):
+        import torch
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs a HIP device (no CPU fallback)")
+        if local_rank >= torch.cuda.device_count():
+            raise SystemExit("bench.py: rank %d has no GPU (local rank %d, %d device(s) visible)" % (rank, local_rank, torch.cuda.device_count()))
+        torch.cuda.set_device(local_rank)
+
+    def sync(self):
+        import torch
+        torch.cuda.synchronize()
+
+    def init_process_group(self, local_rank, timeout):
+        import torch
+        import torch.distributed as dist
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank), timeout=timeout)
+
+    def make_stream(self, n, W, H, seed):
+        from dvo_amd import synthetic
+        return synthetic.make_stream(n, W, H, seed=seed, device="cuda", as_torch=True)
+
+    def aligner(self, *a, **kw):
+        from dvo_amd.batch import StreamedAligner
+        return StreamedAligner(*a, **kw)
+
+    def roofline_leg(self, part, gray_ptr, depth_ptr, n_pairs, steps):
+        return roofline_leg(part, gray_ptr, depth_ptr, n_pairs, steps)
+
+    def leg_config3(self, device, iterations, streams, steps, seed=1234):
+        return leg_config3(device, iterations, streams, steps, seed=seed)
+
+    def n_simds(self, local_rank):
+        import torch
+        return 4 * torch.cuda.get_device_properties(local_rank).multi_processor_count
+
+
+def _load_backend():
+    path = os.environ.get("DVO_BENCH_STUB")
+    if not path:
+        return _HipBackend()
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("dvo_bench_stub", path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod.Backend()
+
+
+ISA_FILE = ROOT / "profiles" / "kernel_isa.json"       # static facts + hash of the level-0 kernel's instructions (tools/isa_count.py --write)
+
+
+def valu_issue_leg(ctx, n_simds, point_waves_per_launch, measured_us, rec):
+    """The bound the level-0 launch actually runs at: VALU issue.  Instruction counts: static, from the library loaded in
+    THIS process (tools/isa_count.py: disassembly of the kernel, its record loop), and dynamic, the committed PMC reading
+    (SQ_INSTS_VALU per point-wave) - used only if the kernel's instruction hash still equals the one the reading was taken on.  Cost of
+    a wave-instruction: dvo_debug_valu_rate, measured now, at the kernel's 5 waves per SIMD.  predicted = count x cost; beside it the
+    measured launch."""
+    out = {}
+    try:
+        sys.path.insert(0, str(ROOT / "tools"))
+        import isa_count
+        from dvo_amd import _cabi
+        facts = isa_count.kernel_facts(_cabi.library_path())
+        committed = json.loads(ISA_FILE.read_text()) if ISA_FILE.exists() else {}
+        same = bool(committed) and committed.get("sha256") == facts["sha256"]
+        out.update({"kernel_sha256": facts["sha256"], "committed_sha256": committed.get("sha256"), "isa_matches_committed": same,
+                    "instr_per_point_static": facts["loop"]["valu_per_point"], "static_by_class_per_point": facts["loop"]["by_class_per_point"]})
+    except Exception as e:                                                  # no llvm-objdump on the box: the probe still runs
+        same = False
+        out["isa_error"] = repr(e)
+    lim = (rec or {}).get("level0_reduction") or {}
+    recorded_ok = same and lim.get("kernel_sha256") == out.get("kernel_sha256")
+    dyn = lim.get("valu_instructions_per_point_wave")
+    out["instr_per_point_recorded"] = dyn
+    out["recorded_reading_is_of_this_kernel"] = bool(recorded_ok)
+    rate = ctx.valu_rate(waves_per_simd=5, iterations=4000)                # ~15 ms per composition
+    out["ns_per_wave_instr"] = rate["mix"]
+    out["ns_per_wave_instr_by_class"] = {k: rate[k] for k in ("fast", "conflict", "slow", "rcp")}
+    # the order of the classes matters: the same composition in small interleaved blocks, and the sum of the class prices (no
+    # interaction at all) - the band the headline figure sits in
+    out["ns_per_wave_instr_other_orders"] = {"small_interleaved_blocks": rate["mix_small_blocks"], "class_priced_sum": rate["mix_class_priced"]}
+    comp = rate["composition"]
+    out["probe_composition"] = dict(zip(("fast", "fast_bank_conflict", "slow", "trans"), comp))
+    # the probe issues the composition of one trip of the record loop as it was when the probe was last updated: same as the kernel's now?
+    out["probe_composition_matches_kernel"] = ("kernel_sha256" in out) and all(
+        facts["loop"]["by_class"].get(k, 0) == v for k, v in out["probe_composition"].items())
+    out["probe"] = ("dvo_debug_valu_rate: ALU-only launch issuing the composition of one trip of the record loop (%d simple, %d simple with "
+                    "both multiplicands in one VGPR bank, %d conversion / bit-field / compare / select / shift, %d v_rcp_f32) arranged as the "
+                    "compiled loop arranges it (per point: unpack cluster, then the FMAs), 5 waves per SIMD, this run" % tuple(comp))
+    ipp = dyn if (recorded_ok and dyn) else out.get("instr_per_point_static")
+    out["instr_per_point"] = ipp
+    out["instr_per_point_source"] = "recorded PMC reading (SQ_INSTS_VALU / point-waves)" if (recorded_ok and dyn) else "static count of the record loop (tools/isa_count.py)"
+    if ipp:
+        pred = point_waves_per_launch * ipp * rate["mix"] / n_simds * 1e-3
+        out.update({"point_waves_per_launch": point_waves_per_launch, "simds": n_simds, "predicted_us": pred, "measured_us": measured_us,
+                    "frac_of_issue_bound": pred / measured_us if measured_us else None,
+                    "frac_of_issue_bound_other_orders": {k: (point_waves_per_launch * ipp * v / n_simds * 1e-3) / measured_us
+                                                         for k, v in out["ns_per_wave_instr_other_orders"].items()} if measured_us else None})
+    return out
+
+
+def level_valid_fractions(part, L, sample=4):
+    """Depth-valid fraction of every pyramid level, measured on the first `sample` frames resident in the first slice's slots."""
+    fr = []
+    for lvl in range(L):
+        v = []
+        for slot in range(sample):
+            d = part.ctx.download_level(slot, lvl, want=("depth",))["depth"]
+            v.append(float((d != 0).mean()))
+        fr.append(sum(v) / len(v))
+    return fr
+
+
+def survey_bytes_per_pair(W, H, L, valid_fraction, iters_per_level):
+    """per GN iteration at a level 2 P + 10 V; per frame pair once: pyramid 3 (P_{l-1} + P_l) for l >= 1 and gradients 9 P_l."""
+    P = []
+    w, h = W, H
+    for _ in range(L):
+        P.append(w * h)
+        w, h = (w + 1) // 2, (h + 1) // 2
+    it = sum(iters_per_level[l] * (2.0 * P[l] + 10.0 * valid_fraction[l] * P[l]) for l in range(L))
+    setup = sum(3.0 * (P[l - 1] + P[l]) for l in range(1, L)) + 9.0 * sum(P)
+    return it + setup, it, setup
+
+
 def main():
     args = parse_args()
     from dvo_amd import launch
+    hw = _load_backend()
 
     # `python bench.py --gpus N` starts its own N ranks (one process per GPU) when no launcher did: fresh child
     # processes under torch.distributed.run, spawned before this process has made any HIP call; rank 0's JSON line is
     # relayed through the inherited stdout.  Fewer than N visible devices is an error, never a 1-GPU measurement.
     if not launch.started_by_launcher() and (args.gpus > 1 or args.spawn):
         try:
-            rc = launch.launch_ranks(args.gpus, str(Path(__file__).resolve()), [a for a in sys.argv[1:] if a != "--spawn"])
+            rc = launch.launch_ranks(args.gpus, str(Path(__file__).resolve()), [a for a in sys.argv[1:] if a != "--spawn"],
+                                     need_devices=(hw.name == "hip"))
         except launch.LaunchError as e:
             raise SystemExit("bench.py: %s" % e)
         raise SystemExit(rc)
@@ -372,43 +526,41 @@ def main():
         launch.check_world(args.gpus)
     except launch.LaunchError as e:
         raise SystemExit("bench.py: %s" % e)
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a HIP device (no CPU fallback)")
-    if local_rank >= torch.cuda.device_count():
-        raise SystemExit("bench.py: rank %d has no GPU (local rank %d, %d device(s) visible)" % (rank, local_rank, torch.cuda.device_count()))
-    torch.cuda.set_device(local_rank)
+    hw.check(local_rank, rank)
+    dev = hw.device
     # under a launcher the process group is always formed (also for one rank: the same RCCL code path as N ranks)
     use_dist = launch.started_by_launcher() or os.environ.get("DVO_BENCH_FORCE_DIST") == "1"
     # (the process group is formed further down, AFTER this rank's device buffers and streams exist: creating the RCCL
     # communicator first costs the whole step ~4 % on MI355X — measured, profiles/r02_experiments.txt)
 
-    from dvo_amd import synthetic
-    from dvo_amd.batch import StreamedAligner, pose_records, PoseGatherer
+    from dvo_amd.batch import pose_records, PoseGatherer
 
     B, W, H, L = args.batch, args.width, args.height, args.levels
     n_frames = B + 1
     n_distinct = args.distinct if args.distinct > 0 else n_frames
     # independent stream per rank (BASELINE config 5), rendered on the device, resident in HBM before timing
-    st = synthetic.make_stream(min(n_distinct, n_frames), W, H, seed=1000 + rank, device="cuda", as_torch=True)
+    st = hw.make_stream(min(n_distinct, n_frames), W, H, 1000 + rank)
     gray, depth = st["gray"], st["depth"]
     if gray.shape[0] < n_frames:                      # optional: tile a shorter render (documented in config)
         reps = (n_frames + gray.shape[0] - 1) // gray.shape[0]
         gray = gray.repeat(reps, 1, 1)[:n_frames].contiguous()
         depth = depth.repeat(reps, 1, 1)[:n_frames].contiguous()
-    torch.cuda.synchronize()
+    hw.sync()
     valid_l0 = float((depth[:-1] != 0).sum().item()) / B            # measured V per pair at level 0
 
-    al = StreamedAligner(st["K"], st["depth_scale"], W, H, L, max_pairs=B, n_streams=args.streams, device=local_rank,
-                         max_iterations=args.iterations, weighting=args.weighting,
-                         approximate_image2_gradient=(args.variant == "v2"),
-                         reference_variant={"v3": "cuda", "gn": "gn"}.get(args.variant, "cpu"),
-                         level_iterations=([int(v) for v in args.level_iterations.split(",")] if args.level_iterations else None))
+    al = hw.aligner(st["K"], st["depth_scale"], W, H, L, max_pairs=B, n_streams=args.streams, device=local_rank,
+                    max_iterations=args.iterations, weighting=args.weighting,
+                    approximate_image2_gradient=(args.variant == "v2"),
+                    reference_variant={"v3": "cuda", "gn": "gn"}.get(args.variant, "cpu"),
+                    level_iterations=([int(v) for v in args.level_iterations.split(",")] if args.level_iterations else None))
+    launch.phase("aligner built (%d pairs in %d streams)" % (B, args.streams))
     if use_dist:
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank), timeout=launch.pg_timeout())
+        hw.init_process_group(local_rank, launch.pg_timeout())
         world = dist.get_world_size()                      # the ranks that actually joined
         if world != args.gpus:
             raise SystemExit("bench.py: %d ranks joined the process group, --gpus %d" % (world, args.gpus))
-    gather = PoseGatherer([B] * world, device="cuda") if use_dist else None
+        launch.phase("process group formed (world size %d, backend %s)" % (world, dist.get_backend()))
+    gather = PoseGatherer([B] * world, device=dev) if use_dist else None
 
     gather_s = [0.0]
 
@@ -435,10 +587,11 @@ def main():
     res = finish()
     if res is not None and not np.all(np.isfinite(res["xi"])):
         raise SystemExit("non-finite poses in warm-up")
+    launch.phase("warm-up done")
 
     def fence():
         al.synchronize()
-        torch.cuda.synchronize()
+        hw.sync()
         if use_dist:
             dist.barrier()
 
@@ -451,6 +604,7 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     elapsed_rank = elapsed
+    launch.phase("timed loop done (%d steps, %.3f ms per step on this rank)" % (args.steps, 1e3 * elapsed / args.steps))
     # the same steps with a fetch of every slice at the end of each (the GPU drains between steps): reported beside `value`
     sync_steps = max(1, min(args.steps, 10))
     ts0 = time.perf_counter()
@@ -459,7 +613,7 @@ def main():
     fence()
     step_synchronous_ms = 1e3 * (time.perf_counter() - ts0) / sync_steps
     if use_dist:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
     iters_total = int(res["iters"].sum())
@@ -469,10 +623,11 @@ def main():
     # so that a multi-GPU record shows each rank's kernel time next to its step time)
     prof = al.parts[0]
     npr = min(B, prof.max_pairs)
-    launches, ms = roofline_leg(prof, gray.data_ptr(), depth.data_ptr(), npr, max(1, min(args.steps, 5)))
+    launches, ms = hw.roofline_leg(prof, gray.data_ptr(), depth.data_ptr(), npr, max(1, min(args.steps, 5)))
+    launch.phase("roofline leg done")
     per_rank = None
     if use_dist:
-        mine = torch.tensor([1e3 * elapsed_rank / args.steps, 1e3 * ms[0] / max(launches[0], 1)], dtype=torch.float64, device="cuda")
+        mine = torch.tensor([1e3 * elapsed_rank / args.steps, 1e3 * ms[0] / max(launches[0], 1)], dtype=torch.float64, device=dev)
         allr = [torch.zeros_like(mine) for _ in range(world)]
         dist.all_gather(allr, mine)
         allr = torch.stack(allr).cpu().numpy()
@@ -482,9 +637,32 @@ def main():
     # --- the build's own production mode beside the metric (N = 1, default workload only): true Gauss-Newton steps on the same
     # kernel (DVO_VARIANT_GN), 1 iteration at the finest level and 2 at the others.  Reported under "production_mode"; never `value`.
     gn_mode = None
-    extras = (world == 1 and rank == 0 and not args.no_extras and args.variant == "v1" and args.weighting == "none"
-              and not args.level_iterations and (W, H, L) == (640, 480, 4))
+    default_workload = (args.variant == "v1" and args.weighting == "none" and not args.level_iterations and (W, H, L) == (640, 480, 4))
+    extras = (world == 1 and rank == 0 and not args.no_extras and default_workload and hw.name == "hip")
     rec = recorded_counters() or {}
+    whole_step = valu = None
+    if rank == 0 and hw.name == "hip":
+        # SURVEY 8(d) bytes of the whole job: per level the measured valid fraction and the iterations that actually ran
+        try:
+            vf = level_valid_fractions(prof, L)
+            sched = [int(v) for v in args.level_iterations.split(",")] if args.level_iterations else [args.iterations] * L
+            sched = (sched + [sched[-1]] * L)[:L]
+            nominal = float(sum(sched))
+            scale_it = (iters_total / B) / nominal if nominal > 0 else 1.0       # pairs that stop early run fewer iterations
+            bpp, b_it, b_setup = survey_bytes_per_pair(W, H, L, vf, [scale_it * v for v in sched])
+            rate = world * B * args.steps / elapsed
+            whole_step = {"algorithmic_bytes_per_pair": bpp, "iteration_bytes_per_pair": b_it, "setup_bytes_per_pair": b_setup,
+                          "valid_fraction_per_level": vf, "gn_iterations_per_pair": iters_total / B,
+                          "achieved": bpp * rate / world / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                          "frac": bpp * rate / world / 1e9 / HBM_PEAK_GBS,
+                          "note": "SURVEY 8(d) bytes per frame pair (2 P + 10 V per iteration and level, pyramid + gradients once) x frame-pairs/s per GPU"}
+        except Exception as e:                                         # pragma: no cover
+            whole_step = {"error": repr(e)}
+        if default_workload or (W, H) == (640, 480):
+            try:
+                valu = valu_issue_leg(prof.ctx, hw.n_simds(local_rank), valid_l0 * npr / 64.0, 1e3 * ms[0] / max(launches[0], 1), rec)
+            except Exception as e:                                     # pragma: no cover
+                valu = {"error": repr(e)}
     if extras:
         from dvo_amd import _cabi
         sched = [1] + [2] * (L - 1)                       # finest level first (tools/exp_gn_schedule.sh)
@@ -519,12 +697,18 @@ def main():
         per_level = {str(l): {"launches": int(launches[l]), "avg_us": (1e3 * ms[l] / launches[l]) if launches[l] else None}
                      for l in range(L)}
         pairs_per_s = world * B * args.steps / elapsed
+        traffic = recorded_traffic(npr, W, H) or {}
+        # a counter reading describes the kernel it was taken on: stale when the instruction hash of the kernel built here differs
+        sha_now = (valu or {}).get("kernel_sha256")
+        lim = rec.get("level0_reduction")
+        if lim is not None:
+            lim = dict(lim, stale=(sha_now is None or lim.get("kernel_sha256") != sha_now))
         out = {
             "metric": "frame-pairs/s (full pyramid GN solve) VGA RGB-D",
             "value": pairs_per_s,
             "unit": "frame-pairs/s",
             "n_gpus": world, "ranks_joined": (dist.get_world_size() if use_dist else 1),
-            "collective": ("RCCL all-gather of pose records, world size %d" % dist.get_world_size()) if use_dist else "none (single process)",
+            "collective": ("%s all-gather of pose records, world size %d" % ("RCCL" if hw.name == "hip" else dist.get_backend(), dist.get_world_size())) if use_dist else "none (single process)",
             "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
@@ -548,17 +732,21 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS,
                          # `traffic`: HBM bytes per launch from rocprofv3 PMC counters.  PMC counters cannot be read from inside this
                          # process: the value is the committed reading of the same launch shape (profiles/pmc_traffic.json), taken
-                         # at `traffic_recorded_at`; null when no reading of this shape exists
-                         "traffic": (recorded_traffic(npr, W, H) or {}).get("hbm_bytes_per_launch"),
-                         "traffic_recorded_at": (recorded_traffic(npr, W, H) or {}).get("commit"),
-                         "traffic_source": (recorded_traffic(npr, W, H) or {}).get("source"),
-                         "kernel": "k_reduce<V1,finest> level 0 (%dx%d), %d pairs per launch" % (W, H, npr),
+                         # at `traffic_recorded_at`; null when no reading of this shape exists; `traffic_stale` when the kernel built
+                         # here is not the one it was taken on
+                         "traffic": traffic.get("hbm_bytes_per_launch"),
+                         "traffic_recorded_at": traffic.get("commit"),
+                         "traffic_source": traffic.get("source"),
+                         "traffic_stale": (traffic.get("hbm_bytes_per_launch") is not None) and (sha_now is None or traffic.get("kernel_sha256") != sha_now),
+                         "kernel": "k_reduce<V1,%s> level 0 (%dx%d), %d pairs per launch" % (args.weighting, W, H, npr),
                          "avg_launch_us": 1e3 * avg_ms, "launches_timed": int(launches[0]),
                          "algorithmic_bytes_per_launch": alg_bytes,
                          "layout_bytes_per_launch": layout_bytes,
                          "achieved_layout_GBs": layout_bytes / (avg_ms * 1e-3) / 1e9,
                          "valid_fraction_level0": valid_l0 / P0, "per_level": per_level,
-                         "recorded_limiter_not_measured_in_this_run": rec.get("level0_reduction")},
+                         "whole_step": whole_step,
+                         "valu_issue": valu,
+                         "recorded_limiter_not_measured_in_this_run": lim},
         }
         if per_rank is not None:
             out["per_rank"] = per_rank
@@ -569,24 +757,28 @@ def main():
     # config 3 (1280x960 x 5 levels, Huber) on EVERY rank when N > 1: north_star asks for both image sizes at 1 / 2 / 4 / 8 GPUs.  Each
     # rank runs its own independent stream (no data-path collective); rank 0 reports the aggregate and the per-rank figures.
     c3_multi = None
-    if (use_dist and ((world > 1 and not args.no_extras) or args.config3_all_ranks) and args.variant == "v1" and args.weighting == "none"
-            and not args.level_iterations and (W, H, L) == (640, 480, 4)):
+    if use_dist and ((world > 1 and not args.no_extras) or args.config3_all_ranks) and default_workload:
         try:
-            c3 = leg_config3(local_rank, args.iterations, args.streams, max(2, min(args.steps, 10)), seed=1234 + rank)
+            c3 = hw.leg_config3(local_rank, args.iterations, args.streams, max(2, min(args.steps, 10)), seed=1234 + rank)
             mine = [c3["frame_pairs_per_s"], c3["roofline"]["frac"], c3["roofline"]["avg_launch_us"], float(c3["batch_pairs"])]
-        except Exception:                                                  # a rank whose leg fails still joins the collective
+        except Exception as e:                                             # a rank whose leg fails still joins the collective
+            print("rank %d: config 3 leg failed: %r" % (rank, e), file=sys.stderr, flush=True)
             c3, mine = None, [float("nan")] * 4
-        tm = torch.tensor(mine, dtype=torch.float64, device="cuda")
+        launch.phase("config 3 done" if c3 is not None else "config 3 FAILED")
+        tm = torch.tensor(mine, dtype=torch.float64, device=dev)
         allc = [torch.zeros_like(tm) for _ in range(world)]
         dist.all_gather(allc, tm)
         allc = torch.stack(allc).cpu().numpy()
         if rank == 0:
             c3_multi = dict(c3 or {"error": "rank 0 leg failed"})
-            c3_multi.update({"n_gpus": world, "frame_pairs_per_s_per_rank": [float(v) for v in allc[:, 0]],
-                             "frame_pairs_per_s": float(np.nansum(allc[:, 0])) if np.all(np.isfinite(allc[:, 0])) else None,
-                             "roofline_frac_per_rank": [float(v) for v in allc[:, 1]],
-                             "level0_avg_launch_us_per_rank": [float(v) for v in allc[:, 2]],
-                             "aggregate_note": "sum over ranks of independent streams run concurrently (weak scaling); `roofline` is rank 0's"})
+            failed = [int(r) for r in np.flatnonzero(~np.isfinite(allc[:, 0]))]
+            c3_multi.update({"n_gpus": world, "frame_pairs_per_s_per_rank": [float(v) if np.isfinite(v) else None for v in allc[:, 0]],
+                             "frame_pairs_per_s": float(np.nansum(allc[:, 0])) if not failed else None,
+                             "failed_ranks": failed,
+                             "roofline_frac_per_rank": [float(v) if np.isfinite(v) else None for v in allc[:, 1]],
+                             "level0_avg_launch_us_per_rank": [float(v) if np.isfinite(v) else None for v in allc[:, 2]],
+                             "aggregate_note": "sum over ranks of independent streams run concurrently (weak scaling); `roofline` is rank 0's; "
+                                               "null when a rank's leg failed (failed_ranks)"})
     if rank == 0:
         if c3_multi is not None:
             out["config3"] = c3_multi
@@ -596,15 +788,16 @@ def main():
             es = max(2, min(args.steps, 10))
             for name, fn in (("student_t_reference", lambda: leg_student_t(st, gray, depth, B, W, H, L, args.iterations, args.streams, local_rank, es)),
                              ("pcie_inclusive", lambda: leg_pcie(st, gray, depth, min(B, 512), W, H, L, args.iterations, local_rank, max(2, min(es, 5)))),
-                             ("config3", lambda: leg_config3(local_rank, args.iterations, args.streams, es))):
+                             ("config3", lambda: leg_config3(local_rank, args.iterations, args.streams, es)),
+                             ("sequence_png", lambda: leg_sequence_png(local_rank))):
                 try:
                     out[name] = fn()
                 except Exception as e:                                         # pragma: no cover
                     out[name] = {"error": repr(e)}
                 torch.cuda.empty_cache()
-        if world == 1 and not args.no_extras:
+        if world == 1 and not args.no_extras and hw.name == "hip":
             out["accuracy"] = fixture_ate(local_rank)
-        if not args.no_cpu_baseline and world == 1:            # CPU baseline: rank 0 at N=1 only
+        if not args.no_cpu_baseline and world == 1 and hw.name == "hip":            # CPU baseline: rank 0 at N=1 only
             cpu_frames = min(args.cpu_pairs + 1, n_frames)
             st_np = {"gray": gray[:cpu_frames].cpu().numpy(),
                      "depth": depth[:cpu_frames].cpu().numpy().view(np.uint16),

@@ -1605,6 +1605,35 @@ int dvo_debug_divide(dvo_ctx* ctx, const float* a, const float* b, float* out, f
     return DVO_OK;
 }
 
+int dvo_debug_valu_rate(dvo_ctx* ctx, int waves_per_simd, int iterations, int* composition, double* ns_per_wave_instr)
+{
+    if (!ctx || !ns_per_wave_instr) return DVO_ERR_INVALID_ARG;
+    if (waves_per_simd < 1 || waves_per_simd > 8 || iterations < 1) return fail(ctx, DVO_ERR_INVALID_ARG, "waves_per_simd in [1,8], iterations >= 1");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    hipDeviceProp_t prop;
+    HIP_TRY(ctx, hipGetDeviceProperties(&prop, ctx->device));
+    const int cus = prop.multiProcessorCount;
+#ifdef DVO_EXPERIMENTS
+    const int n_modes = 24;             // (experiment builds: out[6..13] = other orders and the v_rcp placement cases of tools/ubench/probe_orders.py)
+#else
+    const int n_modes = 6;
+#endif
+    for (int mode = 0; mode < n_modes; ++mode) {
+        const double per_iter = (double)dvo_valu_rate_instructions(mode, (mode == 0) ? composition : nullptr);
+        const int it = (mode == 4) ? (iterations + 1) / 2 : iterations;                              // (128 reciprocals ~ 512 simple instructions)
+        HIP_TRY(ctx, dvo_launch_valu_rate(mode, 4, cus, waves_per_simd, nullptr, ctx->stream));      // warm-up: code in the instruction cache
+        HIP_TRY(ctx, hipEventRecord(ctx->tm_a, ctx->stream));
+        HIP_TRY(ctx, dvo_launch_valu_rate(mode, it, cus, waves_per_simd, nullptr, ctx->stream));
+        HIP_TRY(ctx, hipEventRecord(ctx->tm_b, ctx->stream));
+        HIP_TRY(ctx, hipEventSynchronize(ctx->tm_b));
+        float ms = 0.f;
+        HIP_TRY(ctx, hipEventElapsedTime(&ms, ctx->tm_a, ctx->tm_b));
+        // every SIMD holds waves_per_simd waves, each issuing per_iter instructions per iteration
+        ns_per_wave_instr[mode] = 1e6 * (double)ms / ((double)it * per_iter * waves_per_simd);
+    }
+    return DVO_OK;
+}
+
 int dvo_set_prior(dvo_ctx* ctx, double sigma, const double* last_qt, int n_pairs)
 {
     if (!ctx) return DVO_ERR_INVALID_ARG;

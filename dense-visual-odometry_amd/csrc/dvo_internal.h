@@ -211,6 +211,8 @@ hipError_t dvo_launch_gn_small(const DvoSmallParams& p, int variant, int threads
 hipError_t dvo_launch_debug_divide(const float* a, const float* b, float* out, float* ref, int n, hipStream_t s);
 hipError_t dvo_launch_finish(const DvoPairState* st, int n_pairs, double* xi_out, int* iters_out, double* err_out,
                              hipStream_t s);
+hipError_t dvo_launch_valu_rate(int mode, int iterations, int n_cus, int waves_per_simd, float* sink, hipStream_t s);
+int dvo_valu_rate_instructions(int mode, int* comp4);
 #ifdef DVO_EXPERIMENTS
 // experimental tap formulations of the level-0 reduction (dvo_exp_taps.inc; DVO_EXP_TAPS knob, tools/exp_taps.py)
 hipError_t dvo_launch_exp_convert(const uint8_t* slots, size_t slot_stride, const DvoLevelGeom& g, const int* slot_ids, int n_slots,

@@ -727,11 +727,33 @@ struct PixelGeo {
 struct __attribute__((packed, aligned(4))) u32x2_a4 { uint32_t a, b; };
 struct PixelTaps { u32x2_a4 t0, t1; uint32_t own; };   // (y0,x0)(y0,x1) / (y1,x0)(y1,x1) / prev-frame pixel (V2)
 
+// v_rcp_f32 with a scalar instruction on either side.  A VALU instruction issued right behind a transcendental one stalls the
+// SIMD for ~16 cycles on gfx950 - measured with the issue-rate probe (tools/ubench/probe_orders.py, profiles/r04_ubench_probe_orders.txt,
+// 5 waves per SIMD): one v_rcp_f32 amid simple VALU code costs 13.1 ns, followed by an s_nop 6.2 ns, between two s_nops 4.2 ns
+// (3.4 ns in a run of reciprocals); any scalar instruction in the slot does it, a v_nop does not.  The compiler knows no such rule,
+// hence the three instructions as one asm block (not volatile: an unused reciprocal still disappears).
+#ifndef DVO_RCP_PLAIN
+__device__ __forceinline__ float dvo_rcp(float x)
+{
+    float r;
+#if defined(DVO_RCP_AFTER_ONLY)
+    asm("v_rcp_f32 %0, %1\n\ts_nop 0" : "=v"(r) : "v"(x));
+#elif defined(DVO_RCP_NOP3)
+    asm("s_nop 0\n\tv_rcp_f32 %0, %1\n\ts_nop 3" : "=v"(r) : "v"(x));
+#else
+    asm("s_nop 0\n\tv_rcp_f32 %0, %1\n\ts_nop 0" : "=v"(r) : "v"(x));
+#endif
+    return r;
+}
+#else
+__device__ __forceinline__ float dvo_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+#endif
+
 __device__ __forceinline__ float fast_rcp(float z)
 {
     // v_rcp_f32 (1 ulp) + one Newton step; only used where the oracle tolerance is relative 1e-6, never
     // on the coordinate path.
-    float r = __builtin_amdgcn_rcpf(z);
+    float r = dvo_rcp(z);
     return fmaf(fmaf(-z, r, 1.0f), r, r);
 }
 
@@ -786,7 +808,7 @@ __device__ __forceinline__ void dvo_geo(const DvoLevelGeom& g, const DvoLevelCam
     // (|a/b| beyond 2^+-96, denormals) and patch up inf / NaN / 0: for pixel coordinates (|a/b| < 1e5, |b| ~ 1) they are
     // identities.  A non-finite or zero zp gives NaN here instead of +-inf: invalid either way.  Checked bit for bit
     // against `/` in tests (dvo_debug_divide) and by tools/ubench/quotient3.hip.
-    const float rz0 = __builtin_amdgcn_rcpf(zp);
+    const float rz0 = dvo_rcp(zp);
     const float rz = fmaf(fmaf(-zp, rz0, 1.0f), rz0, rz0);
     const float uw = dvo_div_with_rcp(un, zp, rz);
     const float vw = dvo_div_with_rcp(vn, zp, rz);
@@ -893,7 +915,7 @@ __device__ __forceinline__ void dvo_finish_f(const DvoLevelCam& cam, const Pixel
     // --- J_w at the UN-warped point (utils/jacobian.py:39-42, quirk Q2) ------------------------------
     // x/z and y/z are the normalised coordinates the point was built from (x = xn * z), and 1/z is v_rcp_f32 (1 ulp):
     // both within 2e-7 relative of the reference's float32 quotients, far inside the 1e-5 bound on the increments.
-    const float iz = (VARIANT == 3) ? q.z : __builtin_amdgcn_rcpf(q.z);
+    const float iz = (VARIANT == 3) ? q.z : dvo_rcp(q.z);
     const float a = q.x, b = q.y;
     const float jfx = (VARIANT == 3) ? cam.fx * 0.125f : cam.fx, jfy = (VARIANT == 3) ? cam.fy * 0.125f : cam.fy;   // wave-uniform
     const float p = jfx * gxw, qq = jfy * gyw;
@@ -1666,6 +1688,12 @@ __device__ inline void se3_log(const double* q, const double* t, double* xi)
     xi[3] = phi[0]; xi[4] = phi[1]; xi[5] = phi[2];
 }
 
+// The reference solves with scipy lstsq / gelsy on a FLOAT32 H (base_robust_dvo.py:196-198): LAPACK's rank decision drops every
+// direction whose singular value is below rcond = float32 eps of the largest, and returns the minimum-norm solution of the rest.  For
+// the symmetric positive semi-definite H singular values are eigenvalues: directions with eigenvalue <= 1.19e-7 lambda_max carry no
+// increment (tests/golden/rank_cases.npz: reference runs with cond(H) = inf, 1.5e8 and 1.6e3).
+#define DVO_RANK_RCOND 1.1920928955078125e-07
+
 // Minimum-norm solution of a numerically rank-deficient symmetric 6x6 system through a cyclic Jacobi
 // eigen-decomposition (what LAPACK gelsy, base_robust_dvo.py:196-198, returns for a rank-deficient system).
 // Rare path: kept out of line so its runtime-indexed arrays do not push the common path into scratch.
@@ -1723,7 +1751,7 @@ __device__ __noinline__ void solve6_pinv(const double* hu, const double* b, doub
 #pragma unroll 1
     for (int k = 0; k < 6; ++k) {
         const double e = A[k][k];
-        if (fabs(e) <= 2.220446049250313e-16 * emax) continue;
+        if (!(e > DVO_RANK_RCOND * emax)) continue;           // the reference's rank rule (see solve6)
         double vb = 0.0;
 #pragma unroll 1
         for (int i = 0; i < 6; ++i) vb += V[i][k] * b[i];
@@ -1770,6 +1798,9 @@ __device__ __forceinline__ void solve6(const double* hu, const double* b, double
     bool ok = true;
     double rd[6];                                            // 1 / d_j
     const double dmin = 1e-13 * dmax;
+    double trace = 0.0, det = 1.0;
+#pragma unroll
+    for (int j = 0; j < 6; ++j) trace += a[lo6(j, j)];
 #pragma unroll
     for (int j = 0; j < 6; ++j) {
         double v[6];                                         // v_k = L_jk d_k
@@ -1781,6 +1812,7 @@ __device__ __forceinline__ void solve6(const double* hu, const double* b, double
         }
         ok = ok && (d > dmin);
         d = ok ? d : 1.0;
+        det *= d * (5.0 / trace);                            // (scaled per pivot so that the product stays in range)
         a[lo6(j, j)] = d;
         rd[j] = rcp64(d);
 #pragma unroll
@@ -1791,6 +1823,11 @@ __device__ __forceinline__ void solve6(const double* hu, const double* b, double
             a[lo6(i, j)] = sacc * rd[j];
         }
     }
+    // Full rank under the reference's rule?  lambda_min = det / (product of the other five eigenvalues) >= det (5 / trace)^5 (their
+    // sum is below the trace: AM-GM) and lambda_max <= trace, so lambda_min / lambda_max >= [prod_j d_j (5 / trace)] / 5: when that
+    // exceeds rcond no direction is dropped and the LDL^T solve below IS the reference's answer (fixture frames: 3e-5 against
+    // 1.2e-7).  Otherwise the eigen-decomposition decides exactly (rare: eigenvalue spread beyond ~2e4).
+    ok = ok && (det * 0.2 > DVO_RANK_RCOND);
     if (ok) {
 #pragma unroll
         for (int i = 0; i < 6; ++i) {                       // L z = b
@@ -2697,3 +2734,156 @@ hipError_t dvo_launch_finish(const DvoPairState* st, int n_pairs, double* xi_out
 // rejected formulations of the tap fetch (round 3), kept for A/B builds only: `make EXTRA=-DDVO_EXPERIMENTS OUT=...`
 #include "dvo_exp_taps.inc"
 #endif
+
+// ================================================================================================
+// Issue-rate probe (dvo_debug_valu_rate): what a VALU wave-instruction costs on THIS chip, now
+// ================================================================================================
+// The level-0 reduction is bound by VALU issue: its time is its instruction count times the cost of a
+// wave-instruction at its occupancy.  This kernel measures that cost in the running process, so that bench.py can put the
+// prediction beside the measured launch (roofline.valu_issue).  ALU only, explicit registers, values that stay finite, straight-line
+// code (one backward branch per ~500 instructions).  Four instruction classes:
+//   fast      v_fmac / v_mul / v_add / v_sub / v_and, operands in different VGPR banks
+//   conflict  v_fmac whose two multiplicands sit in ONE bank (register number mod 4): +40-60 % (tools/ubench/vgpr_banks.hip); the
+//             compiler does not allocate by bank, so a real kernel has some (tools/isa_count.py counts them)
+//   slow      conversions, bit-field extract, compare, select, v_fract, shift
+//   rcp       v_rcp_f32 (quarter rate)
+// mode 0 issues the composition of ONE TRIP of k_reduce<V1, unweighted>'s record loop as tools/isa_count.py reads it off the built
+// library - DVO_PROBE_FAST / _CONFLICT / _SLOW / _RCP below; dvo_debug_valu_rate reports the composition it ran, bench.py compares it
+// with the kernel that was built, tests/test_cabi_symbols.py with profiles/kernel_isa.json - modes 1..4 one class alone, mode 5 the
+// composition again in another order (the order matters by ~8 %: tools/ubench/probe_orders.py).
+// The launch places `waves_per_simd` 256-thread workgroups on every CU (dynamic LDS sized so that no CU takes more).
+#define DVO_PROBE_FAST 344
+#define DVO_PROBE_CONFLICT 61
+#define DVO_PROBE_SLOW 136
+#define DVO_PROBE_RCP 8
+#define VR_CLOB "v0","v1","v2","v3","v4","v5","v6","v7","v8","v9","v10","v11","v12","v13","v14","v15","v16","v17","v18","v19","v20","v21","v22","v23","v24","v25","v26","v27","v28","vcc"
+// fast class: accumulators (a x 1 + 0: the values never move), multiplicands v24 = 1.0 (bank 0), v25 = 0.0 (bank 1), accumulators in
+// banks 2 / 3 so that no source pair shares a bank
+#define VR_F0(d) "v_fmac_f32 v" #d ", v24, v25\n"
+#define VR_F1(d) "v_mul_f32 v" #d ", v24, v" #d "\n"
+#define VR_F2(d) "v_add_f32 v" #d ", v25, v" #d "\n"
+#define VR_F3(d) "v_sub_f32 v" #d ", v" #d ", v25\n"
+#define VR_F4(d) "v_and_b32 v" #d ", v27, v" #d "\n"
+#define VR_FAST8A VR_F0(2) VR_F0(3) VR_F1(6) VR_F0(7) VR_F0(10) VR_F2(11) VR_F0(14) VR_F0(15)
+#define VR_FAST8B VR_F0(2) VR_F1(3) VR_F0(6) VR_F0(7) VR_F3(10) VR_F0(11) VR_F4(14) VR_F0(15)
+// conflict class: both multiplicands in bank 0 (v24, v28)
+#define VR_C(d) "v_fmac_f32 v" #d ", v24, v28\n"
+#define VR_CONF4 VR_C(2) VR_C(3) VR_C(6) VR_C(7)
+// slow class: destinations v16..v23, sources the constants v26 (an integer) / v24
+#define VR_SLOW4A "v_cvt_f32_i32 v16, v26\n v_bfe_i32 v17, v26, 8, 12\n v_cvt_f32_ubyte0 v18, v26\n v_fract_f32 v19, v24\n"
+#define VR_SLOW4B "v_cmp_le_u32 vcc, v26, v27\n v_cndmask_b32 v20, v26, v27, vcc\n v_lshlrev_b32 v21, 2, v26\n v_cvt_f32_i32 v22, v26\n"
+#define VR_RCP "s_nop 0\n v_rcp_f32 v23, v24\n s_nop 0\n"            // as dvo_rcp: a scalar instruction on either side
+#define VR_RCP0 "v_rcp_f32 v23, v24\n"                                     // (the bare instruction: placement experiments)
+#define VR_R2(x) x x
+#define VR_R4(x) VR_R2(x) VR_R2(x)
+#define VR_R8(x) VR_R4(x) VR_R4(x)
+#define VR_R16(x) VR_R8(x) VR_R8(x)
+// Mode 0 arranges the composition the way the compiled loop is arranged (tools/isa_count.py prints the class sequence): per point a
+// cluster of conversion-class instructions (the texel unpack), then the FMAs with the bank-conflicted ones among them, the reciprocals
+// in between.  One point: 34 slow, 86 fast, 15 (16) conflict, 2 rcp; a trip = four points = 344 fast, 61 conflict, 136 slow, 8 rcp.
+#define VR_SLOW34 VR_R8(VR_SLOW4A) "v_cvt_f32_i32 v16, v26\n v_cvt_f32_i32 v17, v26\n"
+#define VR_FAST80 VR_R4(VR_FAST8A VR_FAST8B) VR_FAST8A VR_FAST8B
+#define VR_CONF15 VR_CONF4 VR_CONF4 VR_CONF4 VR_C(2) VR_C(3) VR_C(6)
+#define VR_POINT_A VR_SLOW34 VR_FAST80 VR_RCP VR_F0(2) VR_F0(3) VR_F0(6) VR_F1(7) VR_F0(10) VR_F0(11) VR_CONF15 VR_RCP
+#define VR_POINT_B VR_POINT_A
+#define VR_POINT_C VR_SLOW34 VR_FAST80 VR_RCP VR_F0(2) VR_F0(3) VR_F0(6) VR_F1(7) VR_F0(10) VR_F0(11) VR_CONF15 VR_C(7) VR_RCP
+#define VR_TRIP VR_POINT_A VR_POINT_B VR_POINT_A VR_POINT_C
+static_assert(4 * 86 == DVO_PROBE_FAST && 3 * 15 + 16 == DVO_PROBE_CONFLICT && 4 * 34 == DVO_PROBE_SLOW && 4 * 2 == DVO_PROBE_RCP,
+              "VR_TRIP must issue the composition the DVO_PROBE_* constants name");
+// (mode 5, the same composition in small interleaved blocks: 16 fast + 8 slow + 4 conflict = 28;   16 fast + 1 rcp = 17)
+#define VR_X1 VR_FAST8A VR_SLOW4A VR_FAST8B VR_SLOW4B VR_CONF4
+#define VR_X2 VR_FAST8A VR_FAST8B VR_RCP
+#define VR_TRIP_BLOCKS VR_R8(VR_X1) VR_R4(VR_X1) VR_R2(VR_X1) VR_X1 VR_FAST8A VR_SLOW4A VR_FAST8B VR_SLOW4B VR_C(2) VR_R4(VR_X2) VR_X2 VR_SLOW4A VR_SLOW4B VR_FAST8A VR_RCP VR_RCP VR_RCP
+__global__ __launch_bounds__(DVO_BLOCK) void k_valu_rate(int mode, int iterations, float* sink)
+{
+    extern __shared__ float vr_lds[];                    // only sized: caps the workgroups per CU
+    asm volatile("v_mov_b32 v24, 1.0\n v_mov_b32 v25, 0\n v_mov_b32 v26, 0x12345\n v_mov_b32 v27, -1\n v_mov_b32 v28, 0\n"
+                 "v_mov_b32 v0, 1.0\n v_mov_b32 v1, 1.0\n v_mov_b32 v2, 1.0\n v_mov_b32 v3, 1.0\n v_mov_b32 v4, 1.0\n v_mov_b32 v5, 1.0\n v_mov_b32 v6, 1.0\n v_mov_b32 v7, 1.0\n"
+                 "v_mov_b32 v8, 1.0\n v_mov_b32 v9, 1.0\n v_mov_b32 v10, 1.0\n v_mov_b32 v11, 1.0\n v_mov_b32 v12, 1.0\n v_mov_b32 v13, 1.0\n v_mov_b32 v14, 1.0\n v_mov_b32 v15, 1.0\n"
+                 "v_mov_b32 v16, 0\n v_mov_b32 v17, 0\n v_mov_b32 v18, 0\n v_mov_b32 v19, 0\n v_mov_b32 v20, 0\n v_mov_b32 v21, 0\n v_mov_b32 v22, 0\n v_mov_b32 v23, 0\n" ::: VR_CLOB);
+    if (mode == 0) {
+        for (int i = 0; i < iterations; ++i) asm volatile(VR_TRIP ::: VR_CLOB);
+    } else if (mode == 1) {
+        for (int i = 0; i < iterations; ++i) asm volatile(VR_R16(VR_R2(VR_FAST8A VR_FAST8B)) ::: VR_CLOB);          // 512 fast
+    } else if (mode == 2) {
+        for (int i = 0; i < iterations; ++i) asm volatile(VR_R16(VR_R8(VR_CONF4)) ::: VR_CLOB);                     // 512 conflict
+    } else if (mode == 3) {
+        for (int i = 0; i < iterations; ++i) asm volatile(VR_R16(VR_R4(VR_SLOW4A VR_SLOW4B)) ::: VR_CLOB);          // 512 slow
+    } else if (mode == 5) {
+        for (int i = 0; i < iterations; ++i) asm volatile(VR_TRIP_BLOCKS ::: VR_CLOB);      // the composition in small interleaved blocks
+#ifdef DVO_EXPERIMENTS
+    } else if (mode == 6) {
+        // ... grouped per trip: 136 slow, 340 fast, 64 conflict, 8 rcp
+        for (int i = 0; i < iterations; ++i) asm volatile(VR_R16(VR_R2(VR_SLOW4A)) VR_SLOW4B VR_SLOW4B VR_R16(VR_FAST8A VR_FAST8B) VR_R4(VR_FAST8A VR_FAST8B) VR_FAST8A VR_FAST8B VR_F0(2) VR_F0(3) VR_F0(6) VR_F1(7) VR_R16(VR_CONF4) VR_R8(VR_RCP) ::: VR_CLOB);
+    } else if (mode == 7) {
+        // alternating single instructions: fast, slow, fast, fast, slow ... (the finest interleave)
+#define VR_ALT VR_F0(2) "v_cvt_f32_i32 v16, v26\n" VR_F0(3) VR_F1(6) "v_bfe_i32 v17, v26, 8, 12\n" VR_F0(7) VR_F0(10) "v_cvt_f32_ubyte0 v18, v26\n" VR_F2(11) VR_F0(14) "v_fract_f32 v19, v24\n" VR_F0(15)
+        for (int i = 0; i < iterations; ++i) asm volatile(VR_R16(VR_R2(VR_ALT)) VR_R16(VR_CONF4) VR_R8(VR_RCP) ::: VR_CLOB);       // 256 fast + 128 slow + 64 conf + 8 rcp = 456
+    } else if (mode == 22) {
+        // per point, the conversion-class instructions spread between the FMAs (4 : 10) instead of one cluster of 34
+#define VR_POINT_I VR_R8(VR_SLOW4A VR_FAST8A VR_F0(2) VR_F1(3)) "v_cvt_f32_i32 v16, v26\n v_cvt_f32_i32 v17, v26\n" VR_RCP VR_F0(2) VR_F0(3) VR_F0(6) VR_F1(7) VR_F0(10) VR_R4(VR_CONF4) VR_RCP
+        for (int i = 0; i < iterations; ++i) asm volatile(VR_R4(VR_POINT_I) ::: VR_CLOB);
+    } else if (mode == 23) {
+        // ... and the bank-conflicted FMAs spread too (2 per block)
+#define VR_POINT_J VR_R8(VR_SLOW4A VR_FAST8A VR_F0(2) VR_F1(3) VR_C(6) VR_C(7)) "v_cvt_f32_i32 v16, v26\n v_cvt_f32_i32 v17, v26\n" VR_RCP VR_F0(2) VR_F0(3) VR_F0(6) VR_F1(7) VR_F0(10) VR_RCP
+        for (int i = 0; i < iterations; ++i) asm volatile(VR_R4(VR_POINT_J) ::: VR_CLOB);
+    } else if (mode == 8) {
+        for (int i = 0; i < iterations; ++i) asm volatile(VR_R16(VR_FAST8A VR_FAST8B "v_rcp_f32 v23, v24\n") ::: VR_CLOB);                   // 256 fast, 16 rcp each followed by fast
+    } else if (mode == 9) {
+        for (int i = 0; i < iterations; ++i) asm volatile(VR_R16(VR_FAST8A VR_FAST8B) VR_R16(VR_RCP0) ::: VR_CLOB);           // 256 fast, 16 rcp in a row
+    } else if (mode == 10) {
+        for (int i = 0; i < iterations; ++i) asm volatile(VR_R16(VR_FAST8A VR_FAST8B VR_RCP0 VR_SLOW4A) ::: VR_CLOB);         // rcp followed by slow
+    } else if (mode == 11) {
+        for (int i = 0; i < iterations; ++i) asm volatile(VR_R16(VR_FAST8A VR_FAST8B VR_SLOW4A) VR_R16(VR_RCP0) ::: VR_CLOB);
+    } else if (mode == 12) {
+        for (int i = 0; i < iterations; ++i) asm volatile(VR_R16(VR_FAST8A VR_FAST8B VR_RCP0 "s_nop 0\n") ::: VR_CLOB);       // rcp, one idle issue slot, fast
+    } else if (mode == 13) {
+        for (int i = 0; i < iterations; ++i) asm volatile(VR_R16(VR_FAST8A VR_FAST8B VR_SLOW4A) ::: VR_CLOB);                // reference for 10 / 11: no rcp
+    } else if (mode == 14) {
+        for (int i = 0; i < iterations; ++i) asm volatile(VR_R16(VR_FAST8A VR_FAST8B VR_RCP0 "s_nop 1\n") ::: VR_CLOB);
+    } else if (mode == 15) {
+        for (int i = 0; i < iterations; ++i) asm volatile(VR_R16(VR_FAST8A VR_FAST8B VR_RCP0 "s_nop 3\n") ::: VR_CLOB);
+    } else if (mode == 16) {
+        for (int i = 0; i < iterations; ++i) asm volatile(VR_R16(VR_FAST8A VR_FAST8B VR_RCP0 "s_nop 7\n") ::: VR_CLOB);
+    } else if (mode == 17) {
+        for (int i = 0; i < iterations; ++i) asm volatile(VR_R16(VR_FAST8A VR_FAST8B VR_RCP0 "s_mov_b32 s20, 0\n") ::: "s20", VR_CLOB);     // a scalar instruction after it
+    } else if (mode == 18) {
+        for (int i = 0; i < iterations; ++i) asm volatile(VR_R16(VR_FAST8A VR_FAST8B "s_nop 0\n" VR_RCP0 "s_nop 0\n") ::: VR_CLOB);        // nop before and after
+    } else if (mode == 19) {
+        for (int i = 0; i < iterations; ++i) asm volatile(VR_R8(VR_FAST8A VR_FAST8B VR_FAST8A VR_FAST8B VR_RCP0 VR_RCP0 "s_nop 0\n") ::: VR_CLOB);   // pairs of rcp + nop
+    } else if (mode == 20) {
+        for (int i = 0; i < iterations; ++i) asm volatile(VR_R16(VR_FAST8A VR_FAST8B "v_rcp_f32 v23, v24\n v_nop\n") ::: VR_CLOB);         // v_nop after it
+    } else if (mode == 21) {
+        for (int i = 0; i < iterations; ++i) asm volatile(VR_R16(VR_FAST8A VR_FAST8B "v_rcp_f32 v23, v24\n v_cvt_f32_i32 v16, v26\n") ::: VR_CLOB);   // ONE slow op after it
+#endif
+    } else {
+        for (int i = 0; i < iterations; ++i) asm volatile(VR_R16(VR_R8(VR_RCP)) ::: VR_CLOB);                       // 128 rcp
+    }
+    float s;
+    asm volatile("v_add_f32 %0, v2, v3\n v_add_f32 %0, %0, v6\n v_add_f32 %0, %0, v14\n v_add_f32 %0, %0, v16\n v_add_f32 %0, %0, v20\n v_add_f32 %0, %0, v23" : "=v"(s) :: VR_CLOB);
+    if (sink != nullptr && s == 12345.678f) sink[blockIdx.x * DVO_BLOCK + threadIdx.x] = s + vr_lds[0];     // (never true: keeps the work alive)
+}
+
+// instructions one iteration of `mode` issues; composition of mode 0
+int dvo_valu_rate_instructions(int mode, int* comp4)
+{
+    if (comp4) { comp4[0] = DVO_PROBE_FAST; comp4[1] = DVO_PROBE_CONFLICT; comp4[2] = DVO_PROBE_SLOW; comp4[3] = DVO_PROBE_RCP; }
+    if (mode == 6 || mode == 22 || mode == 23) return 548;
+    if (mode == 7) return 456;
+    if (mode == 8 || mode == 9 || mode == 12 || (mode >= 14 && mode <= 19)) return 272;
+    if (mode == 20 || mode == 21) return 288;
+    if (mode == 10 || mode == 11) return 336;
+    if (mode == 13) return 320;
+    return (mode == 0 || mode == 5) ? DVO_PROBE_FAST + DVO_PROBE_CONFLICT + DVO_PROBE_SLOW + DVO_PROBE_RCP : (mode == 4) ? 128 : 512;
+}
+
+hipError_t dvo_launch_valu_rate(int mode, int iterations, int n_cus, int waves_per_simd, float* sink, hipStream_t s)
+{
+    // 160 KB of LDS per CU: a workgroup that asks for 160 KB / waves_per_simd (minus the allocation granule) leaves room for
+    // exactly waves_per_simd of them
+    const size_t lds = (size_t)(160 * 1024 / waves_per_simd) - 512;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_valu_rate), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_valu_rate, dim3((unsigned)(n_cus * waves_per_simd)), dim3(DVO_BLOCK), lds, s, mode, iterations, sink);
+    return hipGetLastError();
+}

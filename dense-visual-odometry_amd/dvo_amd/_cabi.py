@@ -85,6 +85,7 @@ SIGNATURES = {
     "dvo_trace_read": (C.c_int, [_ctx, C.c_int, C.c_void_p]),
     "dvo_profile_enable": (C.c_int, [_ctx, C.c_int]),
     "dvo_profile_read": (C.c_int, [_ctx, _c_i64_p, _c_double_p, C.c_int]),
+    "dvo_debug_valu_rate": (C.c_int, [_ctx, C.c_int, C.c_int, C.c_void_p, _c_double_p]),
     "dvo_timer_start": (C.c_int, [_ctx]),
     "dvo_timer_stop": (C.c_int, [_ctx, _c_float_p]),
 }
@@ -465,6 +466,19 @@ class HipContext:
         out = np.zeros((n_pairs, 8), dtype=np.uint64)
         self._check(self._lib.dvo_debug_small_stamps(self._h, n_pairs, _ptr(out), int(bool(reset))))
         return out
+
+    def valu_rate(self, waves_per_simd: int = 5, iterations: int = 4000) -> dict:
+        """ns per VALU wave-instruction per SIMD at `waves_per_simd` resident waves: for the composition of one trip of the level-0
+        reduction's record loop ("composition": simple, simple with a VGPR bank conflict, conversion-class, v_rcp_f32 instructions)
+        and for each class alone."""
+        out = np.zeros(8, dtype=np.float64)
+        comp = np.zeros(4, dtype=np.int32)
+        self._check(self._lib.dvo_debug_valu_rate(self._h, waves_per_simd, iterations, _ptr(comp), out.ctypes.data_as(_c_double_p)))
+        f, c, s, r = (int(v) for v in comp)
+        priced = (f * out[1] + c * out[2] + s * out[3] + r * out[4]) / max(f + c + s + r, 1)
+        return {"mix": float(out[0]), "fast": float(out[1]), "conflict": float(out[2]), "slow": float(out[3]), "rcp": float(out[4]),
+                "mix_small_blocks": float(out[5]), "mix_class_priced": float(priced), "experiment_orders": [float(out[6]), float(out[7])],
+                "waves_per_simd": waves_per_simd, "composition": [f, c, s, r]}
 
     def timer_start(self):
         self._check(self._lib.dvo_timer_start(self._h))

@@ -27,6 +27,10 @@ from . import _cabi
 from .camera import RGBDCameraModel
 from .lie import Se3
 
+# The reference solves H inc = b with scipy lstsq / gelsy on a FLOAT32 H (base_robust_dvo.py:196-198): LAPACK's rank decision then uses
+# rcond = float32 eps.  The float64 solves of this build (host and device) apply the same rule (tests/golden/rank_cases.npz).
+_RANK_RCOND = float(np.finfo(np.float32).eps)
+
 logger = logging.getLogger(__name__)
 
 
@@ -327,7 +331,7 @@ class RobustDVOHIP:
                     b = b + xo / self._sigma
                     err += 0.5 * self._sigma * float(np.linalg.norm(xo))
                 if np.all(np.isfinite(H)) and np.all(np.isfinite(b)):
-                    inc_xi = scipy.linalg.lstsq(H, b.reshape(6, 1), lapack_driver="gelsy", check_finite=False)[0]
+                    inc_xi = scipy.linalg.lstsq(H, b.reshape(6, 1), cond=_RANK_RCOND, lapack_driver="gelsy", check_finite=False)[0]
                 else:
                     inc_xi = np.full((6, 1), np.nan)
                 inc = Se3.from_se3(inc_xi)

@@ -114,6 +114,54 @@ def read_frame(rgb_path: str, depth_path: str, channel_order: str = "bgr") -> Tu
     return (np.ascontiguousarray(rgb) if channel_order == "rgb" else np.ascontiguousarray(rgb[..., ::-1])), depth
 
 
+def write_tum_dataset(root: Path, frames, depths, T_wc=None, t0: float = 1305031102.0, fps: float = 30.0, depth_lag: float = 0.004,
+                      n_listed: Optional[int] = None, K=None, depth_scale: Optional[float] = None) -> Path:
+    """Writes a dataset in the TUM RGB-D layout (rgb/*.png 8-bit colour, depth/*.png 16-bit, rgb.txt / depth.txt / groundtruth.txt with
+    unsynchronised stamps as a Kinect gives them, optional camera_intrinsics.yaml): what `load_tum_sequence` and the reference's
+    loader (src/test_dvo.py:86-206) read.  `frames`: (n,h,w) gray or (n,h,w,3) BGR u8; `depths` (n,h,w) u16.  `n_listed` > n lists the
+    n files again and again, forwards then backwards (consecutive entries stay consecutive renders), under new stamps: a long
+    sequence for decode-throughput measurements without encoding every frame."""
+    from PIL import Image
+    root = Path(root)
+    (root / "rgb").mkdir(parents=True, exist_ok=True)
+    (root / "depth").mkdir(exist_ok=True)
+    frames, depths = np.asarray(frames), np.asarray(depths)
+    n = frames.shape[0]
+    names = []
+    for k in range(n):
+        tr, td = t0 + k / fps, t0 + k / fps + depth_lag
+        img = frames[k] if frames.ndim == 4 else np.repeat(frames[k][..., None], 3, axis=2)
+        rn, dn = "rgb/%.6f.png" % tr, "depth/%.6f.png" % td
+        Image.fromarray(np.ascontiguousarray(img[..., ::-1]) if frames.ndim == 4 else img).save(root / rn)       # file holds RGB
+        Image.fromarray(depths[k].astype(np.uint16)).save(root / dn)
+        names.append((rn, dn))
+    total = n if n_listed is None else int(n_listed)
+    period = max(2 * (n - 1), 1)
+    with (root / "rgb.txt").open("w") as fr, (root / "depth.txt").open("w") as fd:
+        fr.write("# color images\n# file: 'synthetic'\n# timestamp filename\n")
+        fd.write("# depth maps\n# timestamp filename\n")
+        gt = (root / "groundtruth.txt").open("w") if T_wc is not None else None
+        if gt:
+            gt.write("# ground truth trajectory\n# timestamp tx ty tz qx qy qz qw\n")
+        for i in range(total):
+            k = i % period
+            k = k if k < n else period - k
+            tr, td = t0 + i / fps, t0 + i / fps + depth_lag
+            fr.write("%.6f %s\n" % (tr, names[k][0]))
+            fd.write("%.6f %s\n" % (td, names[k][1]))
+            if gt:
+                T = np.asarray(T_wc[k])
+                q = matrix_to_quat_xyzw(T[:3, :3])
+                gt.write("%.6f %r %r %r %r %r %r %r\n" % ((tr + depth_lag / 2,) + tuple(float(v) for v in T[:3, 3]) + tuple(float(v) for v in q)))
+        if gt:
+            gt.close()
+    if K is not None and depth_scale is not None:
+        K = np.asarray(K, dtype=np.float64)
+        (root / "camera_intrinsics.yaml").write_text("intrinsics:\n" + "".join("  - [%r, %r, %r]\n" % tuple(float(v) for v in row) for row in K[:3, :3]) +
+                                                     "depth_scale: %r\n" % float(depth_scale))
+    return root
+
+
 def iter_frames(seq: TumSequence, channel_order: str = "bgr") -> Iterator[Tuple[np.ndarray, np.ndarray]]:
     for rp, dp in zip(seq.rgb_paths, seq.depth_paths):
         yield read_frame(rp, dp, channel_order)

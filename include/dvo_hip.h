@@ -282,6 +282,15 @@ int dvo_profile_enable(dvo_ctx* ctx, int on);
 /* Sums since the last reset: per level, number of reduction launches, their total device time (ms)
  * and total pixels / depth-valid pixels... read with n = DVO_MAX_LEVELS entries each. Blocks (syncs). */
 int dvo_profile_read(dvo_ctx* ctx, int64_t* launches, double* ms, int reset);
+/* Issue-rate probe: what one VALU wave-instruction costs on this GPU right now, in ns per SIMD, with `waves_per_simd` waves
+ * resident per SIMD.  Four instruction classes: simple (v_fmac / v_mul / v_add ..., operands in different register banks), simple
+ * with both multiplicands in one VGPR bank, conversion / bit-field / compare / select / shift, v_rcp_f32.  out[0]: the composition
+ * of one trip of the level-0 reduction's record loop (compiled into the probe; written to composition[4] when not NULL, so that the
+ * caller can compare it with the kernel that was built: tools/isa_count.py), arranged as the compiled loop arranges it; out[1..4]:
+ * each class alone; out[5]: the composition again, interleaved in small blocks (the order of the classes matters by ~8 %).  ALU-only
+ * launches of `iterations` x ~500 instructions per wave.  bench.py multiplies out[0] by the kernel's instruction count to put the
+ * issue-bound prediction beside the measured launch time (roofline.valu_issue). */
+int dvo_debug_valu_rate(dvo_ctx* ctx, int waves_per_simd, int iterations, int* composition /* [4] or NULL */, double* ns_per_wave_instr /* [8] */);
 /* Event-pair stopwatch on the ctx stream. */
 int dvo_timer_start(dvo_ctx* ctx);
 int dvo_timer_stop(dvo_ctx* ctx, float* ms);

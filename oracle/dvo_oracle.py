@@ -430,11 +430,16 @@ def normal_equations(r: np.ndarray, J: np.ndarray, w: Optional[np.ndarray] = Non
     return H, b, s, n
 
 
-def solve_increment(H: np.ndarray, b: np.ndarray) -> np.ndarray:
-    """scipy.linalg.lstsq(H, b, lapack_driver="gelsy"), base_robust_dvo.py:196-198."""
+RANK_RCOND = float(np.finfo(np.float32).eps)
+
+
+def solve_increment(H: np.ndarray, b: np.ndarray, rcond: float = RANK_RCOND) -> np.ndarray:
+    """scipy.linalg.lstsq(H, b, lapack_driver="gelsy"), base_robust_dvo.py:196-198.  The reference calls it on a float32 H, so LAPACK's
+    rank decision uses rcond = float32 eps: directions whose singular value is below 1.19e-7 of the largest carry no increment
+    (minimum-norm solution).  Restated here on float64 data with that same rcond (pinned by tests/golden/rank_cases.npz)."""
     if not (np.all(np.isfinite(H)) and np.all(np.isfinite(b))):
         return np.full(6, np.nan)
-    return scipy.linalg.lstsq(np.array(H), np.array(b).reshape(6, 1), lapack_driver="gelsy",
+    return scipy.linalg.lstsq(np.array(H, dtype=np.float64), np.array(b, dtype=np.float64).reshape(6, 1), cond=rcond, lapack_driver="gelsy",
                               check_finite=False)[0].reshape(6)
 
 

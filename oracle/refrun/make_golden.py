@@ -36,7 +36,7 @@ vectorised form accumulates in float64 as numba's type inference does, the inter
 accumulates in float32).
 
 Outputs (tests/golden/): frames.npz (inputs), cli_compat.npz, pairs_l4.npz, single_l1.npz, weighted_l4.npz,
-approx_l4.npz, sigma_l4.npz, dense_rj.npz, tiny10.npz, sequence.npz, lie.npz, bilinear_ref.npz, meta.json.
+approx_l4.npz, sigma_l4.npz, dense_rj.npz, tiny10.npz, sequence.npz, lie.npz, bilinear_ref.npz, rank_cases.npz, meta.json.
 """
 import json
 import sys
@@ -342,10 +342,51 @@ def cli_compat_case(cam, data_dir, gt):
     print("C cli-compat pair (1,2): xi=%s" % a["xi"], flush=True)
 
 
+def rank_cases():
+    """a15, the rank decision of the 6x6 solve (base_robust_dvo.py:196-198: scipy lstsq / gelsy on a float32 H, rcond = float32 eps).
+    Three synthetic 160x120 pairs through the reference's own step(), single level, three iterations each:
+      stripes   vertical stripes on a fronto-parallel plane: the image has no vertical gradient, column 1 of J is exactly zero, H has
+                rank 5 under any rule;
+      window    the same with a vertical gradient around two pixels only: cond(H) ~ 1e8, between the float32 rule (1.2e-7: rank 5) and a
+                float64 rule (1e-13: rank 6) - the case in which the two rules give different increments;
+      textured  stripes plus a weak horizontal texture everywhere: cond(H) ~ 1e5, full rank under both rules.
+    Frame 2 is frame 1 shifted by one pixel in x.  Records H32 / b32 / inc32 (what the reference solved) and H64 / inc64 -> rank_cases.npz."""
+    h, w = 120, 160
+    yy, xx = np.mgrid[0:h, 0:w]
+    K = np.array([[130.0, 0.0, 79.5], [0.0, 130.0, 59.5], [0.0, 0.0, 1.0]], dtype=np.float32)
+    cam = RGBDCameraModel(K, 0.0002)
+    depth = np.full((h, w), 10000, dtype=np.uint16)              # 2 m, fronto-parallel
+    base = (127 + 90 * np.sin(xx * 0.35)).astype(np.float64)
+    out = {"intrinsics": K, "depth_scale": np.float64(0.0002), "depth": depth}
+    for name in ("stripes", "window", "textured"):
+        g = base.copy()
+        if name == "window":
+            for (y, x) in [(41, 37), (83, 120)]:
+                g[y, x] += 1.0                                     # two isolated one-grey-level bumps: the only vertical gradient of the image
+        if name == "textured":
+            g += 6.0 * np.sin(yy * 0.5)
+        g1 = np.clip(np.rint(g), 0, 255).astype(np.uint8)
+        g2 = np.roll(g1, 1, axis=1)
+        tf, rec, _ = run_pair(cam, (g1, depth), (g2, depth), levels=1, max_iterations=3)
+        a = pack_records(rec.records)
+        for k in ("T", "n", "H32", "b32", "inc32", "H64", "b64", "inc64"):
+            out["%s_%s" % (name, k)] = a[k]
+        out[name + "_gray1"], out[name + "_gray2"] = g1, g2
+        out[name + "_final_xi"] = se3_to_arrays(tf)["xi"]
+        ev = np.linalg.eigvalsh(a["H64"][0])
+        print("R %-8s iterations %d  eig(H64) min/max %.3g / %.3g = %.3g   inc32[0] %s\n%s inc64[0] %s" % (
+            name, len(rec.records), ev[0], ev[-1], ev[0] / ev[-1], a["inc32"][0], " " * 44, a["inc64"][0]), flush=True)
+    np.savez_compressed(OUT / "rank_cases.npz", **out)
+
+
 def main():
     t_start = time.time()
     OUT.mkdir(parents=True, exist_ok=True)
     install_patches()
+    if "--only-rank" in sys.argv:
+        install_fast_loops()
+        rank_cases()
+        return
     if "--only-cli-compat" in sys.argv:
         install_fast_loops()
         data_dir = REF / "tests" / "test_data"
@@ -522,6 +563,7 @@ def main():
 
     sigma_case(cam, frames)
     cli_compat_case(cam, data_dir, gt)
+    rank_cases()
 
     meta["elapsed_s"] = time.time() - t_start
     with (OUT / "meta.json").open("w") as fp:

@@ -40,12 +40,28 @@ def test_bench_json_contract():
     # nothing in the line is hard-coded prose about counters: recorded readings sit under keys that say so, with their commit
     assert "limiter_measured" not in r
     rl = r["recorded_limiter_not_measured_in_this_run"]
-    assert rl is None or ("commit" in rl and "source" in rl)
-    assert "traffic_recorded_at" in r
+    assert rl is None or ("commit" in rl and "source" in rl and isinstance(rl["stale"], bool))
+    assert "traffic_recorded_at" in r and isinstance(r["traffic_stale"], bool)
+    # the job-level roofline figure (SURVEY 8d bytes per frame pair x value) ...
+    ws = r["whole_step"]
+    assert "error" not in ws, ws
+    assert 3e7 < ws["algorithmic_bytes_per_pair"] < 6e7 and len(ws["valid_fraction_per_level"]) == 4
+    assert abs(ws["frac"] - ws["achieved"] / ws["peak"]) < 1e-12 and 0 < ws["frac"] < 1
+    assert abs(ws["achieved"] * 1e9 - ws["algorithmic_bytes_per_pair"] * d["value"]) < 1e-6 * ws["achieved"] * 1e9
+    # ... and the bound the dominant kernel really runs at, checkable by the driver: instruction count of the kernel that was built
+    # x the cost of a wave-instruction measured in this run, beside the measured launch
+    vi = r["valu_issue"]
+    assert "error" not in vi, vi
+    for k in ("kernel_sha256", "isa_matches_committed", "instr_per_point", "instr_per_point_static", "ns_per_wave_instr", "predicted_us",
+              "measured_us", "frac_of_issue_bound"):
+        assert k in vi, k
+    assert 100 < vi["instr_per_point_static"] < 200 and 0.5 < vi["ns_per_wave_instr"] < 5.0
+    assert abs(vi["measured_us"] - r["avg_launch_us"]) < 1e-9
+    assert vi["isa_matches_committed"] is True, "profiles/kernel_isa.json is not of the kernel that was built: run tools/isa_count.py --write"
     # the rest of north_star's report, on the same clock (N = 1, default workload): config 3, PCIe-inclusive, Student-t
     c3 = d["config3"]
     assert "error" not in c3, c3
-    assert c3["frame_pairs_per_s"] > 0 and c3["batch_pairs"] in (128, 256, 512) and "1280x960" in c3["workload"] and "Huber" in c3["workload"]
+    assert c3["frame_pairs_per_s"] > 0 and c3["batch_pairs"] in (128, 256, 512, 1024) and "1280x960" in c3["workload"] and "Huber" in c3["workload"]
     r3 = c3["roofline"]
     for k in ("avg_launch_us", "algorithmic_bytes_per_launch", "achieved", "peak", "frac"):
         assert k in r3, k
@@ -57,6 +73,9 @@ def test_bench_json_contract():
     stt = d["student_t_reference"]
     assert "error" not in stt, stt
     assert stt["frame_pairs_per_s"] > 0 and stt["gn_iterations_per_pair"] > 0
+    sq = d["sequence_png"]
+    assert "error" not in sq, sq
+    assert sq["best"]["frame_pairs_per_s"] > 0 and sq["from_memory_frame_pairs_per_s"] > 0 and sq["leg_seconds"] < 60
     pm = d["production_mode"]
     assert pm["frame_pairs_per_s"] > 0 and "accuracy_note" not in pm and "recorded_accuracy_not_measured_in_this_run" in pm
 

@@ -93,3 +93,28 @@ def test_header_is_plain_c(tmp_path):
     assert run.returncode == 0, run.stderr
     code = int(run.stdout.split()[0])
     assert code in (0, -2, -3)          # created (GPU box) or "no HIP device" (build container) — never a crash
+
+
+def test_committed_kernel_facts_are_of_the_library_that_was_built():
+    """profiles/kernel_isa.json (instruction hash, static instruction counts of the level-0 reduction's record loop) must describe the
+    kernel in the library that `make` just built - bench.py marks recorded counter readings stale otherwise - and the issue-rate probe
+    (dvo_debug_valu_rate) must issue exactly the composition of that loop.  Refresh with `python tools/isa_count.py --write` and the
+    DVO_PROBE_* constants in csrc/dvo_kernels.hip when the kernel changes."""
+    import json
+    import sys
+    sys.path.insert(0, str(ROOT / "tools"))
+    import isa_count
+    from dvo_amd import _cabi
+    try:
+        facts = isa_count.kernel_facts(_cabi.library_path())
+    except RuntimeError as e:
+        pytest.skip(str(e))
+    committed = json.loads((ROOT / "profiles" / "kernel_isa.json").read_text())
+    assert committed["sha256"] == facts["sha256"], "run `python tools/isa_count.py --write` and commit profiles/kernel_isa.json"
+    assert committed["loop"]["by_class"] == facts["loop"]["by_class"]
+    src = (ROOT / "dense-visual-odometry_amd" / "csrc" / "dvo_kernels.hip").read_text()
+    probe = {k: int(re.search(r"#define DVO_PROBE_%s (\d+)" % k, src).group(1)) for k in ("FAST", "CONFLICT", "SLOW", "RCP")}
+    bc = facts["loop"]["by_class"]
+    assert (probe["FAST"], probe["CONFLICT"], probe["SLOW"], probe["RCP"]) == (bc["fast"], bc["fast_bank_conflict"], bc["slow"], bc["trans"])
+    assert 120 < facts["loop"]["valu_per_point"] < 160 and facts["loop"]["lds"] == 0
+

@@ -169,3 +169,58 @@ def test_sharded_sequence_flow_gloo(tmp_path, golden_dir, world):
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
     for r in range(world):
         assert "rank %d ok" % r in out.stdout
+
+
+def _run_bench_stub(tmp_path, extra_env=None, timeout=300):
+    """`bench.py --gpus 2` under torch.distributed.run on CPU: bench.py's OWN distributed branch with the stand-in backend of
+    tests/bench_stub.py (gloo, world size 2)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parents[1]
+    env = dict(os.environ, DVO_BENCH_STUB=str(root / "tests" / "bench_stub.py"), OMP_NUM_THREADS="1", DVO_PG_TIMEOUT="120")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    env.update(extra_env or {})
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--standalone", "--local-addr", "127.0.0.1", "--nnodes=1", "--nproc-per-node", "2",
+           str(root / "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1", "--batch", "8", "--streams", "2"]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=timeout, cwd=str(root))
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout                              # rank 0 alone prints
+    return json.loads(lines[0]), out.stderr
+
+
+def test_bench_distributed_branch_world_size_two_on_gloo(tmp_path):
+    """bench.py's own N > 1 code: process group formed after the aligner, one pose gather per step inside the timed region, the time
+    of the SLOWEST rank, per-rank step and launch times, config 3 on every rank with its aggregate - and the phase lines a killed
+    SCALE run would leave on stderr."""
+    d, err = _run_bench_stub(tmp_path)
+    assert d["n_gpus"] == 2 and d["ranks_joined"] == 2 and "world size 2" in d["collective"]
+    assert d["scaling"] == "weak" and d["steps"] == 4
+    pr = d["per_rank"]
+    # (the per-step gather keeps the ranks in lock step, so both report about the slower rank's time: rank 1 sleeps 4 ms per step)
+    assert len(pr["ms_per_step"]) == 2 and min(pr["ms_per_step"]) >= 3.5
+    assert d["ms_per_step"] >= pr["ms_per_step_max"] * (1 - 1e-9)                                    # value is priced on the slowest rank
+    assert abs(d["value"] - 2 * 8 / (1e-3 * d["ms_per_step"])) < 1e-6 * d["value"]                   # pairs of ALL ranks / that time
+    assert pr["level0_avg_launch_us"][1] > pr["level0_avg_launch_us"][0]
+    assert d["config"]["pose_gather_ms_per_step"] is not None and d["config"]["pose_gather_ms_per_step"] >= 0
+    c3 = d["config3"]
+    assert c3["n_gpus"] == 2 and c3["frame_pairs_per_s_per_rank"] == [1000.0, 2000.0] and c3["frame_pairs_per_s"] == 3000.0
+    assert c3["failed_ranks"] == [] and np.allclose(c3["roofline_frac_per_rank"], [0.4, 0.41])
+    for k in (0, 1):
+        for what in ("aligner built", "process group formed (world size 2", "timed loop done", "config 3 done"):
+            assert ("rank %d: %s" % (k, what)) in err, (k, what, err[-2000:])
+
+
+def test_bench_distributed_branch_reports_a_failed_config3_rank(tmp_path):
+    """A rank whose config-3 leg raises still joins the gather (NaN record): rank 0 names it, gives no aggregate, and the run ends
+    normally instead of hanging the other ranks in the collective."""
+    d, err = _run_bench_stub(tmp_path, {"DVO_BENCH_STUB_FAIL_C3_RANK": "1"})
+    c3 = d["config3"]
+    assert c3["failed_ranks"] == [1] and c3["frame_pairs_per_s"] is None
+    assert c3["frame_pairs_per_s_per_rank"] == [1000.0, None] and c3["roofline_frac_per_rank"][1] is None
+    assert "rank 1: config 3 FAILED" in err and d["value"] > 0
+

@@ -20,6 +20,11 @@ def _rel(a, b):
                  max(np.linalg.norm(np.asarray(b, dtype=np.float64)), 1e-300))
 
 
+def _cabi_unpack(rec):
+    from dvo_amd import _cabi
+    return _cabi.unpack_record(rec)
+
+
 def _solve(H, b):
     return scipy.linalg.lstsq(H, b.reshape(6, 1), lapack_driver="gelsy")[0].reshape(6)
 
@@ -402,6 +407,53 @@ def test_device_solve_student_t_one_pass_iterations_vs_reference_run(hip, frames
             assert 0.0 < tr[0, j, 30] <= 5e-6, (j, lvl, tr[0, j, 30])
             worst_bound = max(worst_bound, tr[0, j, 30])
     print("one-pass Student-t vs oracle, teacher-forced: worst relative increment error %.2e; worst kept bound %.2e" % (worst_rel, worst_bound))
+
+
+@pytest.mark.parametrize("solver", ["host", "device"])
+def test_rank_rule_of_the_solve_vs_reference_runs(golden_dir, solver):
+    """a15 on both solve paths: the three reference runs of rank_cases.npz (cond(H) = inf / 1.5e8 / 1.6e3; see the CPU test of the same
+    name).  Every iteration's increment against the reference's rank rule (float32 eps) applied to the oracle's float64 normal
+    equations at the pose the solve used, the first one also against the reference run's own numbers."""
+    import dvo_amd
+    g = np.load(golden_dir / "rank_cases.npz")
+    K, scale, depth = g["intrinsics"], float(g["depth_scale"]), g["depth"]
+    with dvo_amd.HipContext(device=0, max_w=160, max_h=120, max_levels=1, n_slots=2, max_pairs=1) as ctx:
+        ctx.set_camera(K[0, 0], K[1, 1], K[0, 2], K[1, 2], K[0, 1], scale)
+        for name in ("stripes", "window", "textured"):
+            g1, g2 = g[name + "_gray1"], g[name + "_gray2"]
+            ctx.upload_frame(0, g1, depth, 1)
+            ctx.upload_frame(1, g2, depth, 1)
+            lv = O.PairLevel(g1, depth, g2, O.level_intrinsics(K, 0), scale)
+            if solver == "device":
+                ctx.trace_enable(3)
+                res = ctx.solve_batch([0], [1], levels=1, max_iterations=3)
+                tr = ctx.trace_read(1)
+                ctx.trace_enable(0)
+                incs = [tr[0, j, 32:38] for j in range(int(res["iters"][0]))]
+                poses = [tr[0, j, 38:50].reshape(3, 4) for j in range(int(res["iters"][0]))]
+                xi = res["xi"][0]
+            else:
+                incs, poses, T = [], [], np.eye(4, dtype=np.float32)
+                est = O.Pose.identity()
+                for j in range(3):
+                    rec = ctx.normal_equations(0, [0], [1], est.matrix()[None])[0]
+                    H, b, _, _, _ = _cabi_unpack(rec)
+                    inc = scipy.linalg.lstsq(H, b.reshape(6, 1), cond=float(np.finfo(np.float32).eps), lapack_driver="gelsy")[0].reshape(6)
+                    incs.append(inc)
+                    poses.append(est.matrix()[:3])
+                    est = O.Pose.from_xi(inc).mul(est)
+                xi = est.log()
+            assert len(incs) == 3
+            for j, (inc, P) in enumerate(zip(incs, poses)):
+                T = np.eye(4, dtype=np.float32)
+                T[:3] = np.asarray(P, dtype=np.float32)
+                r, J, _, _ = O.residuals_and_jacobian(lv, T)
+                Ho, bo, _, _ = O.normal_equations(r, J)
+                assert _rel(inc, O.solve_increment(Ho, bo)) < 1e-5, (name, solver, j)
+                if name != "textured":
+                    assert abs(inc[1]) < 1e-8, (name, solver, j, inc)              # the unconstrained direction carries no step
+            assert _rel(incs[0], g[name + "_inc32"][0]) < 5e-4                     # the reference run's float32 solve, to its rounding
+            np.testing.assert_allclose(xi, g[name + "_final_xi"], rtol=0, atol=2e-6)
 
 
 @pytest.mark.parametrize("solver", ["host", "device"])

@@ -387,3 +387,29 @@ def test_reference_cli_colour_data_flow(frames, golden_dir):
         a[(a * frames["depth_scale"]) > 5.0] = 0                                   # base_dense_visual_odometry.py:59
     est = O.gauss_newton(c["gray_cli_1"], d[0], c["gray_cli_2"], frames["K"], frames["depth_scale"], levels=4, max_iterations=10)
     np.testing.assert_allclose(est.log(), c["tf_xi"], rtol=0, atol=2e-7)
+
+
+def test_rank_rule_of_the_solve_vs_reference_runs(golden_dir):
+    """a15: the reference solves with scipy lstsq / gelsy on a FLOAT32 H (base_robust_dvo.py:196-198), so LAPACK drops every direction
+    whose singular value is below float32 eps of the largest.  rank_cases.npz holds what the reference's own step() solved on three
+    synthetic pairs (oracle/refrun/make_golden.py: rank_cases): vertical stripes on a fronto-parallel plane (rank 5 under any
+    rule), the same with a vertical gradient around two pixels (eigenvalue ratio 6.5e-9: rank 5 under the float32 rule, rank 6 under a
+    float64 one - the increments differ by 4.5e-4 relative), and a weakly textured scene (full rank).  The oracle's solve applies the
+    reference's rule to float64 data and reproduces the reference's float32 increments to their own rounding."""
+    g = np.load(golden_dir / "rank_cases.npz")
+    for name, dropped in (("stripes", True), ("window", True), ("textured", False)):
+        for j in range(3):
+            H, b, ref = g[name + "_H64"][j], g[name + "_b64"][j], g[name + "_inc32"][j].astype(np.float64)
+            inc = O.solve_increment(H, b)
+            assert _rel(inc, ref) < 5e-4, (name, j, _rel(inc, ref))                 # float32 normal equations vs float64 ones
+            full = np.linalg.solve(H + 0.0, b) if np.linalg.matrix_rank(H) == 6 else None
+            if dropped:
+                assert abs(inc[1]) < 1e-8 and abs(ref[1]) < 1e-8                    # no step along the direction the data do not constrain
+            if name == "window":
+                assert _rel(full, ref) > 2e-4 and abs(full[1]) > 5e-7               # a float64 rank rule takes that step: not the reference
+            if name == "textured":
+                assert _rel(full, inc) < 1e-9
+    # and the whole loop of the oracle on the window pair ends where the reference run did
+    est = O.gauss_newton(g["window_gray1"], g["depth"], g["window_gray2"], g["intrinsics"], float(g["depth_scale"]), levels=1, max_iterations=3)
+    np.testing.assert_allclose(est.log(), g["window_final_xi"], rtol=0, atol=2e-6)
+

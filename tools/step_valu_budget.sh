@@ -17,10 +17,11 @@ pass() {
 }
 pass sq1 SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES
 pass sq2 SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_INSTS_SMEM SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT
-pass fetch FETCH_SIZE TCC_HIT_sum TCC_REQ_sum
+pass fetch FETCH_SIZE TCC_HIT_sum
 pass write WRITE_SIZE TCC_MISS_sum
 timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $ARGS > $OUT/trace.log 2>&1 || echo "trace failed" >> $OUT/errors.txt
 python3 tools/step_valu_budget.py $OUT $STEPS $WARM > $OUT/summary.txt 2>&1
 cat $OUT/summary.txt
 cat $OUT/errors.txt 2>/dev/null
 find $OUT -name "*.csv" -size +256k -delete; find $OUT -name "*.db" -delete
+exit 0
