@@ -34,7 +34,7 @@ for f in glob.glob(root + "/trace/**/*kernel_trace.csv", recursive=True):
     for r in rows:
         n = r.get("Kernel_Name", "")
         if "k_reduce" in n:
-            key = short(n)
+            key = short(n) + " grid=" + str(r.get("Grid_Size_X") or r.get("Grid_Size"))       # one instantiation serves every level
             agg[key].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
             meta[key] = (r.get("Grid_Size_X") or r.get("Grid_Size"), r.get("Workgroup_Size_X") or r.get("Workgroup_Size"),
                          r.get("VGPR_Count"), r.get("Accum_VGPR_Count"), r.get("SGPR_Count"), r.get("LDS_Block_Size"), r.get("Scratch_Size"))
@@ -51,6 +51,8 @@ for p in sorted(glob.glob(root + "/pmc_*")):
         cnt = defaultdict(int)
         for r in rows:
             k = short(r.get("Kernel_Name", ""))
+            if "k_reduce" in k:
+                k += " grid=" + str(r.get("Grid_Size") or r.get("Grid_Size_X"))
             agg[k][r["Counter_Name"]] += float(r["Counter_Value"])
             cnt[(k, r["Counter_Name"])] += 1
         print("== PMC pass %s (per-dispatch averages)" % p.split("/")[-1])
