@@ -23,6 +23,138 @@ from .lie import Se3
 from .batch import compose_trajectory
 
 
+class Decoded:
+    """A frame handed over by a DecoderPool: views into a shared-memory slot, and the call that gives the slot back."""
+    __slots__ = ("img", "depth", "release")
+
+    def __init__(self, img, depth, release):
+        self.img, self.depth, self.release = img, depth, release
+
+
+def _decoder_worker(task_q, result_q, shm_name, img_shape, depth_shape, slot_bytes):
+    """Worker process of DecoderPool: runs picklable zero-argument decoders, writes (image, depth) into its slot of the shared block."""
+    from multiprocessing import shared_memory
+    shm = shared_memory.SharedMemory(name=shm_name)
+    n_img = int(np.prod(img_shape))
+    try:
+        while True:
+            task = task_q.get()
+            if task is None:
+                return
+            gen, tid, slot, fn = task
+            try:
+                img, dep = fn()
+                base = slot * slot_bytes
+                np.ndarray(img_shape, np.uint8, shm.buf, base)[...] = img
+                np.ndarray(depth_shape, np.uint16, shm.buf, base + ((n_img + 63) // 64) * 64)[...] = dep
+                result_q.put((gen, tid, slot, None))
+            except BaseException as e:                      # surfaced in the parent, in sequence order
+                result_q.put((gen, tid, slot, "{}: {}".format(type(e).__name__, e)))
+    finally:
+        shm.close()
+
+
+class DecoderPool:
+    """`workers` PROCESSES decoding frames (PNG pairs) into a ring of shared-memory slots, results handed out in sequence order.
+    Threads stop scaling at ~1.2 k VGA frames/s on this image's PIL (the conversion to an array holds the interpreter lock:
+    profiles/r04_sequence_png.txt); processes scale with the cores.  Tasks must be picklable zero-argument callables, e.g.
+    functools.partial(tum.read_frame, rgb_path, depth_path, "bgr").
+
+    Create the pool BEFORE the process touches the GPU: the workers are started through multiprocessing's forkserver, which execs
+    a fresh interpreter, and a process that has initialised HIP must not exec (nor fork) - the workers themselves never import
+    torch or load the HIP library."""
+
+    def __init__(self, workers: int, img_shape, depth_shape, slots: int = 0, method: str = "forkserver"):
+        import multiprocessing as mp
+        from multiprocessing import shared_memory
+        if workers < 1:
+            raise ValueError("workers >= 1 required")
+        self.img_shape, self.depth_shape = tuple(img_shape), tuple(depth_shape)
+        n_img = int(np.prod(self.img_shape))
+        self._off_depth = ((n_img + 63) // 64) * 64
+        self.slot_bytes = ((self._off_depth + 2 * int(np.prod(self.depth_shape)) + 4095) // 4096) * 4096
+        self.slots = slots if slots > 0 else 4 * workers
+        self._shm = shared_memory.SharedMemory(create=True, size=self.slots * self.slot_bytes)
+        ctx = mp.get_context(method)
+        self._tasks, self._results = ctx.Queue(), ctx.Queue()
+        self._procs = [ctx.Process(target=_decoder_worker, args=(self._tasks, self._results, self._shm.name, self.img_shape, self.depth_shape,
+                                                                 self.slot_bytes), daemon=True) for _ in range(workers)]
+        for p in self._procs:
+            p.start()
+        self._closed = False
+        self._gen = 0
+
+    def imap(self, tasks: Iterable) -> Iterator:
+        """Yields a Decoded per task, in order; at most `slots` frames are decoded ahead of the consumer.  Items that are not callable
+        (already decoded (image, depth) tuples) pass through in place."""
+        from collections import deque
+        free = deque(range(self.slots))
+        self._gen += 1                                     # results of an earlier, abandoned imap are recognised and dropped
+        gen = self._gen
+        ready, it = {}, iter(tasks)
+        submitted = yielded = 0
+        exhausted, held = False, None                     # held: a task taken from `tasks` that waits for a free slot
+        while True:
+            while not exhausted:
+                if held is None:
+                    try:
+                        held = next(it)
+                    except StopIteration:
+                        exhausted = True
+                        break
+                if callable(held):
+                    if not free:
+                        break
+                    self._tasks.put((gen, submitted, free.popleft(), held))
+                else:
+                    ready[submitted] = ("item", held)
+                held = None
+                submitted += 1
+            if yielded == submitted:
+                if exhausted:
+                    return
+                raise RuntimeError("DecoderPool: every slot is held by the consumer (release a Decoded before asking for the next)")
+            while yielded not in ready:
+                g, tid, slot, err = self._results.get()
+                if g == gen:
+                    ready[tid] = ("slot", slot, err)
+            r = ready.pop(yielded)
+            yielded += 1
+            if r[0] == "item":
+                yield r[1]
+                continue
+            _, slot, err = r
+            if err is not None:
+                free.append(slot)
+                raise OSError("frame decoder failed: " + err)
+            base = slot * self.slot_bytes
+            img = np.ndarray(self.img_shape, np.uint8, self._shm.buf, base)
+            dep = np.ndarray(self.depth_shape, np.uint16, self._shm.buf, base + self._off_depth)
+            yield Decoded(img, dep, (lambda s=slot: free.append(s)))
+
+    def close(self):
+        if self._closed:
+            return
+        self._closed = True
+        for _ in self._procs:
+            self._tasks.put(None)
+        for p in self._procs:
+            p.join(timeout=5.0)
+            if p.is_alive():
+                p.terminate()
+        try:
+            self._shm.close()
+            self._shm.unlink()
+        except (FileNotFoundError, BufferError):
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+
 class FrameWindows:
     """Iterates over windows of consecutive frames of a sequence, decoded by a background thread into a small ring of
     window buffers (page-locked when `alloc` is `_cabi.pinned_array`).  Consecutive windows share one frame: window k holds
@@ -32,9 +164,10 @@ class FrameWindows:
     iteration is (image_window, depth_window, n_frames_in_window): views into a ring slot that stay valid until `depth`
     further windows have been requested (`ring` = 3 by default: one being aligned, one uploaded, one being filled)."""
 
-    def __init__(self, frames: Iterable, window_pairs: int, alloc: Callable = None, ring: int = 3, workers: int = 0):
+    def __init__(self, frames: Iterable, window_pairs: int, alloc: Callable = None, ring: int = 3, workers=0):
         """`frames` may also yield zero-argument callables returning (image, depth) — e.g. PNG decoders; with `workers` > 0
-        they run in a pool of that many threads (PIL releases the GIL while decoding), results kept in sequence order."""
+        they run in a pool of that many threads (PIL releases the GIL while inflating), with `workers` a DecoderPool in its worker
+        processes; results are kept in sequence order either way."""
         if window_pairs < 1 or ring < 2:
             raise ValueError("window_pairs >= 1 and ring >= 2 required")
         self._frames = self._resolve(iter(frames), workers)
@@ -52,6 +185,9 @@ class FrameWindows:
 
     @staticmethod
     def _resolve(it, workers):
+        if isinstance(workers, DecoderPool):
+            yield from workers.imap(it)
+            return
         if workers <= 0:
             for item in it:
                 yield item() if callable(item) else item
@@ -92,30 +228,44 @@ class FrameWindows:
             done = False
             while not done and not self._stop:
                 t0 = time.perf_counter()
-                items = [] if carry is None else [carry]
-                while len(items) < self._w + 1:
-                    try:
-                        items.append(next(self._frames))
-                    except StopIteration:
-                        done = True
-                        break
-                if len(items) < 2:
-                    break
-                if not self._bufs:
-                    self._make_buffers(items[0][0], items[0][1])
-                slot = self._free.get()
-                if slot is None:
-                    break
-                ib, db = self._bufs[slot]
-                for k, (img, dep) in enumerate(items):
+                slot, k, ib, db = None, 0, None, None
+                while k < self._w + 1:
+                    release = None
+                    if carry is not None:
+                        img, dep = carry
+                        carry = None
+                    else:
+                        try:
+                            item = next(self._frames)
+                        except StopIteration:
+                            done = True
+                            break
+                        if isinstance(item, Decoded):
+                            img, dep, release = item.img, item.depth, item.release
+                        else:
+                            img, dep = item
+                    if not self._bufs:
+                        self._make_buffers(img, dep)
+                    if slot is None:
+                        slot = self._free.get()
+                        if slot is None:
+                            if release is not None:
+                                release()
+                            return
+                        ib, db = self._bufs[slot]
                     if img.shape != ib.shape[1:] or dep.shape != db.shape[1:]:
                         raise ValueError("frame {} of the window has shape {} / {}, expected {} / {}".format(
                             k, img.shape, dep.shape, ib.shape[1:], db.shape[1:]))
-                    ib[k] = img
+                    ib[k] = img                                 # frames go into the (page-locked) window as they arrive
                     db[k] = dep
-                carry = (ib[len(items) - 1].copy(), db[len(items) - 1].copy())       # the next window may land in another slot
+                    if release is not None:
+                        release()
+                    k += 1
+                if k < 2:
+                    break
+                carry = (ib[k - 1].copy(), db[k - 1].copy())     # the next window may land in another slot
                 self.decode_seconds += time.perf_counter() - t0
-                if not self._put((slot, len(items))):
+                if not self._put((slot, k)):
                     break
         except BaseException as e:                  # surfaced in the consumer thread
             self._err = e
@@ -166,7 +316,7 @@ def align_windows(aligner, windows: Iterable[Tuple[np.ndarray, np.ndarray, int]]
 
 
 def align_shard(make_aligner: Callable, source: Callable, n_total: int, rank: int, world: int, window_pairs: int,
-                colour: bool, alloc: Callable = None, workers: int = 0, streams: int = 1):
+                colour: bool, alloc: Callable = None, workers=0, streams: int = 1):
     """BASELINE config 4, one rank's part: rank `rank` of `world` aligns the contiguous range of pairs `shard_pairs` gives it
     (frames lo..hi: one boundary frame is shared with the neighbouring rank).  `source(lo, hi)` yields the frames (or decoder
     thunks) lo..hi-1; `make_aligner(height, width, window_pairs)` builds the aligner once the frame size is known.

@@ -832,7 +832,7 @@ def test_run_sequence_on_a_tum_layout_dataset(tmp_path):
     K = np.asarray(st["K"], dtype=np.float64)
     cam.write_text("intrinsics:\n" + "".join("  - [%r, %r, %r]\n" % tuple(float(v) for v in row) for row in K) +
                    "depth_scale: %r\n" % float(st["depth_scale"]))
-    for extra in ([], ["--gpus", "1", "--spawn"]):
+    for extra in ([], ["--gpus", "1", "--spawn"], ["--decoder-processes", "3", "--window", "4"]):      # threads / launcher / worker processes
         out_dir = tmp_path / ("out%d" % len(extra))
         cmd = [sys.executable, str(root / "tools" / "run_sequence.py"), "--tum-dir", str(data), "--camera", str(cam),
                "--out", str(out_dir), "--window", "5", "--decoders", "4"] + extra

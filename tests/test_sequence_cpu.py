@@ -133,3 +133,31 @@ def test_frame_windows_decoder_thread_ends_when_the_consumer_stops_early():
         time.sleep(0.05)
     assert not fw._thread.is_alive()
     assert threading.active_count() < 20
+
+
+def _decode_stub(k, fail_at=-1):
+    """picklable stand-in for a PNG decoder (module level: the pool's worker processes import it by name)"""
+    if k == fail_at:
+        raise OSError("cannot identify image file %d" % k)
+    return np.full((4, 6, 3), k % 251, dtype=np.uint8), np.full((4, 6), k, dtype=np.uint16)
+
+
+def test_decoder_pool_of_processes_keeps_order_and_surfaces_errors():
+    """DecoderPool: decoders run in worker PROCESSES (started through the forkserver before anything touches a GPU), frames come back
+    through shared memory in sequence order - also with fewer slots than frames in flight and with already-decoded items mixed in -
+    and a failing decoder raises in the consumer at its place in the sequence."""
+    import functools
+    with sequence.DecoderPool(3, (4, 6, 3), (4, 6), slots=5) as pool:
+        tasks = [functools.partial(_decode_stub, k) if k % 4 else _decode_stub(k) for k in range(57)]
+        seen = []
+        for img, dep, m in sequence.FrameWindows(tasks, 8, workers=pool):
+            ids = [int(dep[k, 0, 0]) for k in range(m)]
+            assert all(int(img[k, 1, 2, 0]) == ids[k] % 251 for k in range(m))
+            seen += [(a, a + 1) for a in ids[:-1]]
+        assert seen == [(a, a + 1) for a in range(56)]
+        # a second sequence through the same pool, one decoder failing
+        bad = [functools.partial(_decode_stub, k, 13) for k in range(30)]
+        with pytest.raises(OSError, match="cannot identify image file 13"):
+            list(sequence.FrameWindows(bad, 4, workers=pool))
+    assert all(not p.is_alive() for p in pool._procs)
+

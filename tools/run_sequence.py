@@ -42,7 +42,9 @@ def parse_args():
     ap.add_argument("--level-iterations", type=str, default=None, help="comma-separated iterations per level, finest first (overrides --iterations)")
     ap.add_argument("--window", type=int, default=128, help="frame pairs per batched upload + solve")
     ap.add_argument("--streams", type=int, default=2, help="HIP streams (slices of a window) per GPU")
-    ap.add_argument("--decoders", type=int, default=8, help="PNG decoder threads (TUM mode)")
+    ap.add_argument("--decoders", type=int, default=16, help="PNG decoder threads (TUM mode; PIL stops scaling at ~16: profiles/r04_sequence_png.txt)")
+    ap.add_argument("--decoder-processes", type=int, default=0, help="decode in this many worker PROCESSES instead of threads (TUM mode): "
+                                                                     "scales with the cores; the pool is started before the GPU is touched")
     ap.add_argument("--colour", action="store_true", help="feed BGR frames (conversion + depth clamp on the device) "
                                                            "also for --fixture / --synthetic (B = G = R)")
     ap.add_argument("--camera", type=Path, default=None, help="camera_intrinsics.yaml (TUM mode; default fr1)")
@@ -73,6 +75,12 @@ def main():
 
     rank, local_rank, world = launch.rank_env()
     launch.mark_rank("started")
+    # decoder worker processes are started BEFORE anything in this process initialises HIP (a process that has must not exec)
+    pool = None
+    if args.tum_dir and args.decoder_processes > 0:
+        seq0 = tum.load_tum_sequence(args.tum_dir, size=args.size)
+        f0 = tum.read_frame(seq0.rgb_paths[0], seq0.depth_paths[0], "bgr")
+        pool = sequence.DecoderPool(args.decoder_processes, f0[0].shape, f0[1].shape)
     use_dist = launch.started_by_launcher() or os.environ.get("DVO_FORCE_DIST") == "1"
     if use_dist:
         try:
@@ -130,8 +138,9 @@ def main():
         order = "rgb" if compat else "bgr"
 
         def source(lo, hi):                          # decoded lazily, by the decoder pool, for this rank's range only
+            import functools
             for k in range(lo, hi):
-                yield (lambda k=k: tum.read_frame(seq.rgb_paths[k], seq.depth_paths[k], order))
+                yield functools.partial(tum.read_frame, seq.rgb_paths[k], seq.depth_paths[k], order)      # (picklable: worker processes)
 
     def make_aligner(h, w, window):
         return StreamedAligner(K, scale, w, h, args.levels, max_pairs=window, n_streams=args.streams, device=local_rank,
@@ -141,7 +150,9 @@ def main():
                                level_iterations=([int(v) for v in args.level_iterations.split(",")] if args.level_iterations else None))
 
     res = sequence.align_shard(make_aligner, source, n_total, rank if use_dist else 0, world if use_dist else 1, args.window,
-                               colour, alloc=_cabi.pinned_array, workers=args.decoders, streams=args.streams)
+                               colour, alloc=_cabi.pinned_array, workers=(pool if pool is not None else args.decoders), streams=args.streams)
+    if pool is not None:
+        pool.close()
     n_local, decode_s = res["hi"] - res["lo"], res["decode_seconds"]
     T_rel, iters = res["T"], res["iters"]
 
