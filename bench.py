@@ -137,25 +137,28 @@ def cpu_baseline(stream_np, levels, iterations, n_pairs):
         out["per_iteration_ms_vga_level0"]["blas_threads"] = blas_threads
     except Exception as e:                                        # pragma: no cover
         out["per_iteration_ms_vga_level0"]["threads_all_error"] = repr(e)
-    # --- every core: independent pairs over worker processes (pairs are independent, as on the GPU).  The pool is capped at 16
-    # workers: one GPU's share of the node's cores on this pool (gpurun's own guidance for a 1-GPU box), and what the memory cap
-    # and process guard of a box allow safely.  Plain child processes running oracle/cpu_worker.py: NumPy + oracle only, never
-    # torch / HIP.  Each reports the seconds of its own range (start-up and a warm-up pair excluded); they start together.
+    # --- every core of ONE GPU's share of the node: independent pairs over worker processes (pairs are independent, as on the GPU).
+    # An MI355X node carries 8 GPUs, so the share is usable_cpus / 8 (32 of 256 on this pool), capped at 64; each worker aligns one
+    # pair of the sample or more.  Plain child processes running oracle/cpu_worker.py: NumPy + oracle only, never torch / HIP.  Each
+    # reports the seconds of its own range (start-up and a warm-up pair excluded); they start together.
     try:
         import subprocess
         import tempfile
-        workers = max(1, min(16, usable, n_pairs))
+        workers = max(1, min(64, usable // 8 if usable >= 8 else usable))
+        n_all = min(max(n_pairs, workers), g.shape[0] - 1)              # at least one pair per worker
+        workers = min(workers, n_all)
         with tempfile.TemporaryDirectory() as tmp:
             path = os.path.join(tmp, "cpu_sample.npz")
-            np.savez(path, gray=g[:n_pairs + 1], depth=d[:n_pairs + 1], K=K, depth_scale=sc)
-            bounds = [round(i * n_pairs / workers) for i in range(workers + 1)]
+            np.savez(path, gray=g[:n_all + 1], depth=d[:n_all + 1], K=K, depth_scale=sc)
+            bounds = [round(i * n_all / workers) for i in range(workers + 1)]
             env = dict(os.environ, OMP_NUM_THREADS="1", OPENBLAS_NUM_THREADS="1", MKL_NUM_THREADS="1")
             procs = [subprocess.Popen([sys.executable, str(ROOT / "oracle" / "cpu_worker.py"), path, str(bounds[i]), str(bounds[i + 1]),
                                        str(levels), str(iterations)], stdout=subprocess.PIPE, env=env, text=True) for i in range(workers)]
             secs = [float(p.communicate(timeout=600)[0].strip().splitlines()[-1]) for p in procs]
         dtp = max(secs)
-        out["all_workers"] = {"value": n_pairs / dtp, "unit": "frame-pairs/s", "cores": workers,
-                              "sample": "the same %d pairs over %d single-threaded worker processes, slowest worker %.1f s" % (n_pairs, workers, dtp)}
+        out["all_workers"] = {"value": n_all / dtp, "unit": "frame-pairs/s", "cores": workers,
+                              "sample": "%d pairs of the same stream over %d single-threaded worker processes (one GPU's share of the node's %d usable "
+                                        "CPUs: 1/8), slowest worker %.1f s" % (n_all, workers, usable, dtp)}
     except Exception as e:                                            # pragma: no cover
         out["all_workers"] = {"error": repr(e)}
     # --- 1280x960, 5 levels (BASELINE config 3 shape): the VGA frames upsampled 2x (same texture statistics), one thread ------
@@ -798,7 +801,7 @@ def main():
         if world == 1 and not args.no_extras and hw.name == "hip":
             out["accuracy"] = fixture_ate(local_rank)
         if not args.no_cpu_baseline and world == 1 and hw.name == "hip":            # CPU baseline: rank 0 at N=1 only
-            cpu_frames = min(args.cpu_pairs + 1, n_frames)
+            cpu_frames = min(max(args.cpu_pairs, 64) + 1, n_frames)            # (the all-workers leg wants a pair per worker)
             st_np = {"gray": gray[:cpu_frames].cpu().numpy(),
                      "depth": depth[:cpu_frames].cpu().numpy().view(np.uint16),
                      "K": st["K"], "depth_scale": st["depth_scale"]}

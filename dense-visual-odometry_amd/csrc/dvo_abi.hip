@@ -1590,13 +1590,13 @@ int dvo_solve_batch(dvo_ctx* ctx, int n_pairs, const int* prev_slot, const int* 
 
 int dvo_debug_divide(dvo_ctx* ctx, const float* a, const float* b, float* out, float* ref, int n)
 {
-    if (!ctx || !a || !b || !out || !ref || n <= 0) return DVO_ERR_INVALID_ARG;
+    if (!ctx || !b || !out || !ref || n <= 0) return DVO_ERR_INVALID_ARG;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     float* d = nullptr;
     HIP_TRY(ctx, hipMalloc((void**)&d, (size_t)n * 4 * sizeof(float)));
-    hipError_t e = hipMemcpyAsync(d, a, (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream);
+    hipError_t e = a ? hipMemcpyAsync(d, a, (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream) : hipSuccess;
     if (e == hipSuccess) e = hipMemcpyAsync(d + n, b, (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream);
-    if (e == hipSuccess) e = dvo_launch_debug_divide(d, d + n, d + 2 * (size_t)n, d + 3 * (size_t)n, n, ctx->stream);
+    if (e == hipSuccess) e = dvo_launch_debug_divide(a ? d : nullptr, d + n, d + 2 * (size_t)n, d + 3 * (size_t)n, n, ctx->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(out, d + 2 * (size_t)n, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(ref, d + 3 * (size_t)n, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);

@@ -765,10 +765,11 @@ __device__ __forceinline__ void unpack_tap(uint32_t p, float& I, float& gx, floa
 }
 
 // a / b, correctly rounded, from the refined reciprocal rb = v_rcp_f32(b) + one Newton step: one residual correction of the
-// product (Markstein's sequence).  tools/ubench/quotient3.hip compared it on the device with the IEEE division over 3.4e10
-// operand pairs in and far beyond the projection's ranges and over EVERY float32 mantissa of b (incl. the all-ones patterns the
-// theorem excepts) x 192 numerators: no mismatch (profiles/r03_experiments.txt); the GPU suite repeats a 50 M-pair check
-// (test_projection_division_is_bit_identical_to_ieee).  DVO_DIV_TWO_STEPS restores the two-correction form of rounds 1-2.
+// product (Markstein's sequence), which is correctly rounded for EVERY numerator when rb is the float nearest to 1 / b - and on
+// gfx950 it is, for every one of the 2^23 mantissas of b (decided exactly on the device: tools/ubench/quotient3.hip,
+// profiles/r04_ubench_quotient3.txt: 0 exceptions; the raw v_rcp_f32 is not the nearest float for 897 675 of them; repeated in the
+// GPU suite through dvo_debug_divide with a == NULL).  The same tool compared the quotient itself with the IEEE division over
+// 3.4e10 operand pairs and every mantissa of b x 192 numerators: no mismatch.  DVO_DIV_TWO_STEPS restores the two-correction form.
 __device__ __forceinline__ float dvo_div_with_rcp(float a, float b, float rb)
 {
     const float q0 = a * rb;
@@ -944,13 +945,15 @@ __device__ __forceinline__ void dvo_finish(const DvoLevelCam& cam, const PixelGe
     dvo_finish_f<VARIANT, NEED_J>(cam, q, f, i1, o);
 }
 
-// Test hook: out[i] = the kernels' quotient a[i]/b[i]; ref[i] = the compiler's IEEE division.
+// Test hook: out[i] = the kernels' quotient a[i]/b[i]; ref[i] = the compiler's IEEE division.  a == NULL: out[i] = the refined
+// reciprocal of b[i] itself (what dvo_geo shares between its two quotients), ref[i] = 1 / b[i] by the IEEE division.
 __global__ void k_debug_divide(const float* a, const float* b, float* out, float* ref, int n)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const float rz0 = __builtin_amdgcn_rcpf(b[i]);
+    const float rz0 = dvo_rcp(b[i]);
     const float rz = fmaf(fmaf(-b[i], rz0, 1.0f), rz0, rz0);
+    if (a == nullptr) { out[i] = rz; ref[i] = 1.0f / b[i]; return; }
     out[i] = dvo_div_with_rcp(a[i], b[i], rz);
     ref[i] = a[i] / b[i];
 }

@@ -417,13 +417,14 @@ class HipContext:
         q = None if last_qt is None else _as(last_qt, np.float64).reshape(-1, 7)
         self._check(self._lib.dvo_set_prior(self._h, float(sigma), _ptr(q), 0 if q is None else q.shape[0]))
 
-    def debug_divide(self, a: np.ndarray, b: np.ndarray):
-        """(kernel quotient, IEEE quotient) computed on the device for float32 arrays a, b."""
-        a = _as(a, np.float32).reshape(-1)
+    def debug_divide(self, a, b: np.ndarray):
+        """(kernel quotient, IEEE quotient) computed on the device for float32 arrays a, b; a = None: (the projection's refined
+        reciprocal of b, the IEEE 1 / b)."""
         b = _as(b, np.float32).reshape(-1)
-        out = np.empty_like(a)
-        ref = np.empty_like(a)
-        self._check(self._lib.dvo_debug_divide(self._h, _ptr(a), _ptr(b), _ptr(out), _ptr(ref), a.shape[0]))
+        a = None if a is None else _as(a, np.float32).reshape(-1)
+        out = np.empty_like(b)
+        ref = np.empty_like(b)
+        self._check(self._lib.dvo_debug_divide(self._h, _ptr(a), _ptr(b), _ptr(out), _ptr(ref), b.shape[0]))
         return out, ref
 
     def trace_enable(self, cap: int):

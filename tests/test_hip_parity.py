@@ -724,6 +724,25 @@ def test_projection_division_is_bit_identical_to_ieee(hip):
     assert np.array_equal(out[:3], ref[:3]) and not np.isfinite(out[3]) and not np.isfinite(ref[3])
 
 
+def test_refined_reciprocal_is_the_nearest_float_for_every_mantissa(hip):
+    """Markstein: the one-correction quotient q = fma(fma(-b, a rb, a), rb, a rb) is correctly rounded for EVERY numerator a if rb is
+    the float nearest to 1 / b.  Exhaustive over the 2^23 mantissas of b (the reciprocal's error does not depend on the exponent; two
+    exponents and a sign are checked anyway): the projection's refined reciprocal (v_rcp_f32 + one Newton step) against the exactly
+    decided nearest float - 1 - b q is exact in float64 for float32 b and q, so q is nearest iff |1 - b q| is not larger than for
+    either neighbour.  This turns the sampled "no mismatch seen" of rounds 2-3 into a proof for the whole operand space."""
+    ctx, _ = hip
+    m = np.arange(1 << 23, dtype=np.uint32)
+    for expo, sign in ((127, 0), (121, 0), (130, 1)):
+        b = ((np.uint32(sign) << np.uint32(31)) | (np.uint32(expo) << np.uint32(23)) | m).view(np.float32)
+        rb, ieee = ctx.debug_divide(None, b)
+        bd, q = b.astype(np.float64), rb.astype(np.float64)
+        e0 = np.abs(1.0 - bd * q)
+        up = (rb.view(np.uint32) + np.uint32(1)).view(np.float32).astype(np.float64)
+        dn = (rb.view(np.uint32) - np.uint32(1)).view(np.float32).astype(np.float64)
+        assert np.all(e0 <= np.abs(1.0 - bd * up)) and np.all(e0 <= np.abs(1.0 - bd * dn)), (expo, sign)
+        assert np.array_equal(rb.view(np.uint32), ieee.view(np.uint32))          # = the IEEE division 1 / b, bit for bit
+
+
 # ------------------------------------------------------------------------------------------------
 # variant V3: the reference's numba.cuda kernel semantics (parity unpinned: oracle restatement only)
 # ------------------------------------------------------------------------------------------------

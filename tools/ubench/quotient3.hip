@@ -62,6 +62,46 @@ __global__ void k_mantissa(unsigned seed, int n_num, unsigned long long* cnt)
     }
 }
 
+// Markstein's theorem makes the one-correction quotient correctly rounded for EVERY numerator if rz == RN(1 / b).  Exhaustive
+// over the 2^23 mantissas of b (the reciprocal's error pattern does not depend on the exponent): is the refined reciprocal
+// r1 = fma(fma(-b, r0, 1), r0, r0), r0 = v_rcp_f32(b), the float nearest to 1 / b?  Decided exactly: 1 - b q is exact in float64 for
+// float32 b, q, so q is nearest iff |1 - b q| <= |1 - b q'| for both neighbours q'.  Exceptions are written out (up to `cap`).
+__global__ void k_rcp_nearest(unsigned long long* cnt, unsigned* exc, unsigned cap)
+{
+    const unsigned m = blockIdx.x * blockDim.x + threadIdx.x;
+    if (m >= (1u << 23)) return;
+    const float b = __uint_as_float(0x3f800000u | m);
+    const float r0 = __builtin_amdgcn_rcpf(b);
+    const float r1 = fmaf(fmaf(-b, r0, 1.0f), r0, r0);
+    const double e0 = fabs(1.0 - (double)b * (double)r1);
+    const double ep = fabs(1.0 - (double)b * (double)__uint_as_float(__float_as_uint(r1) + 1u));
+    const double em = fabs(1.0 - (double)b * (double)__uint_as_float(__float_as_uint(r1) - 1u));
+    if (!(e0 <= ep && e0 <= em)) {
+        const unsigned long long k = atomicAdd(&cnt[0], 1ull);
+        if (k < cap) exc[k] = m;
+    }
+    // (and the raw v_rcp_f32, for the record)
+    const double f0 = fabs(1.0 - (double)b * (double)r0);
+    const double fp = fabs(1.0 - (double)b * (double)__uint_as_float(__float_as_uint(r0) + 1u));
+    const double fm = fabs(1.0 - (double)b * (double)__uint_as_float(__float_as_uint(r0) - 1u));
+    if (!(f0 <= fp && f0 <= fm)) atomicAdd(&cnt[1], 1ull);
+}
+
+// for the excepted mantissas of b: EVERY numerator mantissa (a in [1, 2): quotients on both sides of 1, i.e. both rounding positions)
+__global__ void k_exceptions_all_numerators(const unsigned* exc, unsigned n_exc, unsigned long long* cnt)
+{
+    const unsigned ma = blockIdx.x * blockDim.x + threadIdx.x;
+    if (ma >= (1u << 23)) return;
+    const float a = __uint_as_float(0x3f800000u | ma);
+    for (unsigned k = 0; k < n_exc; ++k) {
+        const float b = __uint_as_float(0x3f800000u | exc[k]);
+        const float r0 = __builtin_amdgcn_rcpf(b);
+        const float r1 = fmaf(fmaf(-b, r0, 1.0f), r0, r0);
+        const float p1 = fmaf(fmaf(-b, a * r1, a), r1, a * r1);
+        if (__float_as_uint(p1) != __float_as_uint(a / b)) atomicAdd(&cnt[0], 1ull);
+    }
+}
+
 int main()
 {
     unsigned long long* cnt; unsigned long long h[4];
@@ -84,5 +124,33 @@ int main()
     CHK(hipMemcpy(h, cnt, 32, hipMemcpyDeviceToHost));
     printf("every mantissa of b x %d numerators x 2: %.3g pairs; mismatches: 5-instr(r1) %llu   3-instr(r1) %llu   3-instr(r2) %llu   (control: %llu)\n",
            n_num, 2.0 * n_num * 8388608.0, h[0], h[1], h[2], h[3]);
+    // exhaustive: is the refined reciprocal the nearest float to 1 / b, for every mantissa of b?
+    const unsigned cap = 1u << 20;
+    unsigned* exc;
+    CHK(hipMalloc(&exc, cap * sizeof(unsigned)));
+    CHK(hipMemset(cnt, 0, 32));
+    hipLaunchKernelGGL(k_rcp_nearest, dim3((1u << 23) / 256), dim3(256), 0, 0, cnt, exc, cap);
+    CHK(hipDeviceSynchronize());
+    CHK(hipMemcpy(h, cnt, 32, hipMemcpyDeviceToHost));
+    printf("refined reciprocal r1 == RN(1/b) over all 2^23 mantissas of b: %llu exceptions (raw v_rcp_f32: %llu not nearest)\n", h[0], h[1]);
+    unsigned n_exc = (unsigned)(h[0] < cap ? h[0] : cap);
+    if (n_exc) {
+        unsigned first[8];
+        CHK(hipMemcpy(first, exc, sizeof(unsigned) * (n_exc < 8 ? n_exc : 8), hipMemcpyDeviceToHost));
+        printf("  first excepted mantissas:");
+        for (unsigned k = 0; k < (n_exc < 8 ? n_exc : 8); ++k) printf(" 0x%06x", first[k]);
+        printf("\n");
+        // every numerator mantissa against every excepted divisor, in chunks of 256 divisors per launch
+        unsigned long long total = 0;
+        for (unsigned off = 0; off < n_exc; off += 256) {
+            CHK(hipMemset(cnt, 0, 32));
+            const unsigned n = (n_exc - off < 256) ? n_exc - off : 256;
+            hipLaunchKernelGGL(k_exceptions_all_numerators, dim3((1u << 23) / 256), dim3(256), 0, 0, exc + off, n, cnt);
+            CHK(hipDeviceSynchronize());
+            CHK(hipMemcpy(h, cnt, 8, hipMemcpyDeviceToHost));
+            total += h[0];
+        }
+        printf("  every numerator mantissa (2^23) x the %u excepted divisors = %.3g quotients: %llu differ from the IEEE division\n", n_exc, 8388608.0 * n_exc, total);
+    }
     return 0;
 }
