@@ -113,6 +113,7 @@ struct dvo_ctx {
         std::vector<float> Tinit;
         std::vector<double> prior;
     } last;
+    bool refetch_invalid = false;        // the last fetch solved flagged pairs again: the device buffers now hold THAT compacted solve
     int64_t st_fallbacks = 0;            // fetched solves in which at least one pair had to be solved again
     int64_t st_fallback_pairs = 0;       // ... and how many pairs that were
     unsigned long long* d_small_stamps = nullptr;   // DVO_SMALL_STAMPS: [max_pairs][8] phase clocks of k_gn_small (diagnostic)
@@ -1391,6 +1392,7 @@ int dvo_solve_batch_enqueue(dvo_ctx* ctx, int n_pairs, const int* prev_slot, con
     key.trace_rows = 0;
     ctx->last_key = key;
     ctx->last_has_init = (T_init != nullptr);
+    ctx->refetch_invalid = false;
     ctx->last_moment = (weight_mode == DVO_WEIGHT_STUDENT_T) && variant != DVO_VARIANT_V3;
     if (ctx->last_moment) {
         // host copies for the per-pair fallback of dvo_solve_batch_fetch
@@ -1511,6 +1513,9 @@ int dvo_solve_batch_fetch(dvo_ctx* ctx, int n_pairs, float* T_out, double* xi_ou
     if (!ctx) return DVO_ERR_INVALID_ARG;
     if (n_pairs <= 0 || n_pairs > ctx->max_pairs) return fail(ctx, DVO_ERR_INVALID_ARG, "n_pairs %d outside [1,%d]", n_pairs, ctx->max_pairs);
     HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (ctx->refetch_invalid)
+        return fail(ctx, DVO_ERR_BAD_STATE, "dvo_solve_batch_fetch: this solve was already fetched and some of its pairs were solved again (Student-t "
+                    "fallback); the device buffers hold that partial solve - fetch once per enqueue");
     const bool student_t = ctx->last_moment && n_pairs == ctx->last_key.n_pairs;
     int rc = fetch_results(ctx, n_pairs, student_t);
     if (rc) return rc;
@@ -1531,6 +1536,7 @@ int dvo_solve_batch_fetch(dvo_ctx* ctx, int n_pairs, float* T_out, double* xi_ou
         else if (ctx->h_pair_flags[i] & 1) bound_only.push_back(i);
     }
     if (bound_only.empty() && shape.empty()) return DVO_OK;
+    ctx->refetch_invalid = true;
     ctx->st_fallbacks += 1;
     ctx->st_fallback_pairs += (int64_t)(bound_only.size() + shape.size());
     if (ctx->knobs.st_debug)

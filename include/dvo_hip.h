@@ -227,7 +227,8 @@ int dvo_solve_batch(dvo_ctx* ctx, int n_pairs, const int* prev_slot, const int* 
                     int max_iterations, double tolerance, int max_increased_steps_allowed, int variant,
                     int weight_mode, double weight_param, const float* T_init, float* T_out, double* xi_out,
                     int* iters_out, double* err_out);
-/* Asynchronous form: enqueue only; results land in device buffers, fetched by dvo_solve_batch_fetch. */
+/* Asynchronous form: enqueue only; results land in device buffers, fetched by dvo_solve_batch_fetch - once per enqueue (a second
+ * fetch of a DVO_WEIGHT_STUDENT_T solve whose first fetch had to solve pairs again is refused: DVO_ERR_BAD_STATE). */
 int dvo_solve_batch_enqueue(dvo_ctx* ctx, int n_pairs, const int* prev_slot, const int* cur_slot, int levels,
                             int max_iterations, double tolerance, int max_increased_steps_allowed, int variant,
                             int weight_mode, double weight_param, const float* T_init);

@@ -340,6 +340,14 @@ def test_student_t_fallback_refuses_frames_that_changed_since_enqueue():
         with pytest.raises(dvo_amd.DVOHipError) as e:
             ctx.solve_batch_fetch(1)
         assert e.value.code == -5 and "uploaded again" in str(e.value)
+        # ... and a second fetch of a solve whose first fetch solved pairs again is refused (the device buffers hold the re-solve)
+        ctx.upload_frame(1, gray[1], depth[1], 4)
+        ctx.solve_batch_enqueue(np.array([0], np.int32), np.array([1], np.int32), *args)
+        ctx.solve_batch_fetch(1)
+        assert ctx.student_t_fallback_pairs() >= 1
+        with pytest.raises(dvo_amd.DVOHipError) as e:
+            ctx.solve_batch_fetch(1)
+        assert e.value.code == -5 and "fetch once per enqueue" in str(e.value)
         # an ordinary pair: nothing is flagged, the same call order is legal
         from dvo_amd import synthetic
         st2 = synthetic.make_stream(2, 640, 480, seed=5)
