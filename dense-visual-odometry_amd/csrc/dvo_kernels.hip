@@ -709,6 +709,12 @@ __device__ __forceinline__ uint2 dvo_rec_load(const uint2* p)
     return *p;
 }
 
+template <bool NT>
+__device__ __forceinline__ unsigned long long dvo_rec_load64(const unsigned long long* p)
+{
+    return NT ? __builtin_nontemporal_load(p) : *p;
+}
+
 struct PixelOut {
     float r;
     float J[6];
@@ -894,9 +900,9 @@ struct PixelTapsF {
     float own_gx, own_gy;
 };
 
-template <int VARIANT, bool NEED_J>
+template <int VARIANT, bool NEED_J, typename I1>
 __device__ __forceinline__ void dvo_finish_f(const DvoLevelCam& cam, const PixelGeo& q, const PixelTapsF& t,
-                                             unsigned i1, PixelOut& o)
+                                             I1 i1, PixelOut& o)                 // i1: the previous frame's intensity, integer or already a float
 {
     // --- bilinear weights (cpu_robust...:202-254) ------------------------------------------------------
     const float ax = q.ax, ay = q.ay;                      // uw - floor(uw), vw - floor(vw): exact
@@ -931,9 +937,9 @@ __device__ __forceinline__ void dvo_finish_f(const DvoLevelCam& cam, const Pixel
     o.J[5] = fmaf(qq, a, -(p * b));
 }
 
-template <int VARIANT, bool NEED_J>
+template <int VARIANT, bool NEED_J, typename I1>
 __device__ __forceinline__ void dvo_finish(const DvoLevelCam& cam, const PixelGeo& q, const PixelTaps& t,
-                                           unsigned i1, PixelOut& o)
+                                           I1 i1, PixelOut& o)
 {
     PixelTapsF f;
     unpack_tap(t.t0.a, f.I[0], f.gx[0], f.gy[0]);
@@ -942,7 +948,7 @@ __device__ __forceinline__ void dvo_finish(const DvoLevelCam& cam, const PixelGe
     unpack_tap(t.t1.b, f.I[3], f.gx[3], f.gy[3]);
     f.own_gx = f.own_gy = 0.0f;
     if (NEED_J && VARIANT == 1) { float Ip; unpack_tap(t.own, Ip, f.own_gx, f.own_gy); }
-    dvo_finish_f<VARIANT, NEED_J>(cam, q, f, i1, o);
+    dvo_finish_f<VARIANT, NEED_J, I1>(cam, q, f, i1, o);
 }
 
 // Test hook: out[i] = the kernels' quotient a[i]/b[i]; ref[i] = the compiler's IEEE division.  a == NULL: out[i] = the refined
@@ -1127,7 +1133,9 @@ __global__ __launch_bounds__(DVO_BLOCK, (VARIANT == 2) ? 2 : DVO_REDUCE_WAVES_PE
     // owns 256 consecutive records per group and lane L takes records L, L+64, L+128, L+192 of them, so every load
     // instruction of the wave (the 8-byte records and, because neighbouring records are neighbouring pixels, the two
     // 8-byte tap rows of the packed plane) covers whole cache lines.
-    const int lane_ = threadIdx.x & 63, wave_ = threadIdx.x >> 6;
+    // (the wave index through readfirstlane: the compiler then knows that the loop's bounds and the prefetch condition are
+    // wave-uniform - scalar branches, no exec-mask bookkeeping and no register copies to keep "inactive lanes'" records)
+    const int lane_ = threadIdx.x & 63, wave_ = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const DvoPointRec* list = reinterpret_cast<const DvoPointRec*>(prev + p.g.off_list);
     const int count = p.list_count[p.prev_slot[pair] * DVO_LIST_LEVELS + p.level];
     // The G = ceil(count / 1024) record groups of the pair are split into contiguous, count-balanced ranges: workgroup blk takes
@@ -1140,57 +1148,63 @@ __global__ __launch_bounds__(DVO_BLOCK, (VARIANT == 2) ? 2 : DVO_REDUCE_WAVES_PE
     const int rec0 = g_lo * DVO_PX_PER_BLOCK + wave_off;
     // the records of the next group are requested one group ahead, so their latency is covered by the arithmetic of
     // the current group and only the dependent tap gathers are waited for
-    uint2 rn[DVO_PX_PER_THREAD];
+    unsigned long long rn[DVO_PX_PER_THREAD];     // 64-bit values: the loop-carried registers ARE the loads' destination pairs
 #pragma unroll
-    for (int j = 0; j < DVO_PX_PER_THREAD; ++j) rn[j] = make_uint2(0u, 0u);
+    for (int j = 0; j < DVO_PX_PER_THREAD; ++j) rn[j] = 0ull;
     const bool nt_records = p.nt_records != 0;                            // launch-uniform
     if (g_lo < g_hi && rec0 < count) {
         if (nt_records) {
 #pragma unroll
-            for (int j = 0; j < DVO_PX_PER_THREAD; ++j) rn[j] = dvo_rec_load<true>(reinterpret_cast<const uint2*>(list + rec0 + j * 64 + lane_));
+            for (int j = 0; j < DVO_PX_PER_THREAD; ++j) rn[j] = dvo_rec_load64<true>(reinterpret_cast<const unsigned long long*>(list + rec0 + j * 64 + lane_));
         } else {
 #pragma unroll
-            for (int j = 0; j < DVO_PX_PER_THREAD; ++j) rn[j] = dvo_rec_load<false>(reinterpret_cast<const uint2*>(list + rec0 + j * 64 + lane_));
+            for (int j = 0; j < DVO_PX_PER_THREAD; ++j) rn[j] = dvo_rec_load64<false>(reinterpret_cast<const unsigned long long*>(list + rec0 + j * 64 + lane_));
         }
     }
     for (int grp = g_lo; grp < g_hi; ++grp) {
         const int seg = grp * DVO_PX_PER_BLOCK + wave_off;
         if (seg >= count) break;                                          // wave-uniform
-        uint2 rc[DVO_PX_PER_THREAD];
-#pragma unroll
-        for (int j = 0; j < DVO_PX_PER_THREAD; ++j) rc[j] = rn[j];
-        {
-            const int segn = seg + DVO_PX_PER_BLOCK;
-            if (grp + 1 < g_hi && segn < count) {                         // (reads past `count` stay inside DVO_LIST_SLACK)
-                if (nt_records) {
-#pragma unroll
-                    for (int j = 0; j < DVO_PX_PER_THREAD; ++j) rn[j] = dvo_rec_load<true>(reinterpret_cast<const uint2*>(list + segn + j * 64 + lane_));
-                } else {
-#pragma unroll
-                    for (int j = 0; j < DVO_PX_PER_THREAD; ++j) rn[j] = dvo_rec_load<false>(reinterpret_cast<const uint2*>(list + segn + j * 64 + lane_));
-                }
-            }
-        }
         // phase A for all pixels of the lane, then all tap loads back to back (memory-level parallelism: the
-        // dependent gathers of 4 pixels are in flight together), then phase B
+        // dependent gathers of 4 pixels are in flight together), then the request for the next group's records, then phase B.
+        // Phase A takes everything it needs out of the records (the previous frame's intensity as a float), so the next
+        // group's records are loaded into the SAME registers: no rotation of a current / next pair (8 v_mov_b64 per trip).
         PixelGeo geo[DVO_PX_PER_THREAD];
         PixelTaps taps[DVO_PX_PER_THREAD];
+        float i1f[DVO_PX_PER_THREAD];
         float jv3[(VARIANT == 2) ? DVO_PX_PER_THREAD : 1][6];
 #pragma unroll
         for (int j = 0; j < DVO_PX_PER_THREAD; ++j) {
             // V1 / V2: records past `count` are the list's NaN padding (k_list_build) and fail the bounds test by themselves
             const bool live = (VARIANT == 2) ? ((seg + j * 64 + lane_) < count) : true;
-            const unsigned pix = rc[j].y;
+            const unsigned pix = (unsigned)(rn[j] >> 32);
+            i1f[j] = (float)(pix >> 24);
             const unsigned xi = pix & 0xfffu, yi = (pix >> 12) & 0xfffu;
             if constexpr (VARIANT == 2) {
                 // the numba.cuda kernel converts depth in float32 (dvo_geo_v3): it starts from the raw depth again
                 const unsigned d = live ? (unsigned)depth_prev[yi * (unsigned)p.g.w + xi] : 0u;
                 dvo_geo_v3(p.g, cam, p.depth_scale, T, gray_prev, (int)xi, (int)yi, d, geo[j], jv3[j]);
             } else {
-                dvo_geo<SKEW, VARIANT == 3>(p.g, cam, T, (float)xi, (float)yi, __uint_as_float(rc[j].x), live, geo[j]);
+                dvo_geo<SKEW, VARIANT == 3>(p.g, cam, T, (float)xi, (float)yi, __uint_as_float((unsigned)rn[j]), live, geo[j]);
             }
             dvo_load_taps(p.g, packed_cur, geo[j], taps[j]);
             if (VARIANT == 1) taps[j].own = geo[j].ok ? packed_prev[yi * (unsigned)p.g.pitch + xi] : 0u;
+        }
+        {
+            // the records of the next group: behind the tap gathers in the memory queue (loads return in order, so phase B waits
+            // for the taps only), their latency covered by phase B
+            // UNCONDITIONAL (after the wave's last group: that group once more, an address that is valid by construction and whose
+            // data is not used): a load under a condition keeps the old registers alive for the lanes / trips that do not load, which
+            // costs the copies this arrangement is there to remove
+            __builtin_amdgcn_sched_barrier(0);          // (not hoisted into phase A, where the current records are still live)
+            const int segn0 = seg + DVO_PX_PER_BLOCK;
+            const int segn = (grp + 1 < g_hi && segn0 < count) ? segn0 : seg;     // wave-uniform  (reads past `count` stay inside DVO_LIST_SLACK)
+            if (nt_records) {
+#pragma unroll
+                for (int j = 0; j < DVO_PX_PER_THREAD; ++j) rn[j] = dvo_rec_load64<true>(reinterpret_cast<const unsigned long long*>(list + segn + j * 64 + lane_));
+            } else {
+#pragma unroll
+                for (int j = 0; j < DVO_PX_PER_THREAD; ++j) rn[j] = dvo_rec_load64<false>(reinterpret_cast<const unsigned long long*>(list + segn + j * 64 + lane_));
+            }
         }
         float rkeep[SCALE_PASS ? DVO_PX_PER_THREAD : 1];
         if constexpr (SCALE_PASS) {
@@ -1201,7 +1215,7 @@ __global__ __launch_bounds__(DVO_BLOCK, (VARIANT == 2) ? 2 : DVO_REDUCE_WAVES_PE
         for (int j = 0; j < DVO_PX_PER_THREAD; ++j) {
             if (geo[j].ok) {                                  // depth != 0 (camera_model.py:195) and in bounds
                 PixelOut o;
-                dvo_finish<VARIANT, !SCALE_PASS>(cam, geo[j], taps[j], rc[j].y >> 24, o);
+                dvo_finish<VARIANT, !SCALE_PASS>(cam, geo[j], taps[j], i1f[j], o);
                 if constexpr (VARIANT == 2) {
 #pragma unroll
                     for (int k = 0; k < 6; ++k) o.J[k] = jv3[j][k];
@@ -2755,9 +2769,9 @@ hipError_t dvo_launch_finish(const DvoPairState* st, int n_pairs, double* xi_out
 // with the kernel that was built, tests/test_cabi_symbols.py with profiles/kernel_isa.json - modes 1..4 one class alone, mode 5 the
 // composition again in another order (the order matters by ~8 %: tools/ubench/probe_orders.py).
 // The launch places `waves_per_simd` 256-thread workgroups on every CU (dynamic LDS sized so that no CU takes more).
-#define DVO_PROBE_FAST 344
-#define DVO_PROBE_CONFLICT 61
-#define DVO_PROBE_SLOW 136
+#define DVO_PROBE_FAST 340
+#define DVO_PROBE_CONFLICT 64
+#define DVO_PROBE_SLOW 129
 #define DVO_PROBE_RCP 8
 #define VR_CLOB "v0","v1","v2","v3","v4","v5","v6","v7","v8","v9","v10","v11","v12","v13","v14","v15","v16","v17","v18","v19","v20","v21","v22","v23","v24","v25","v26","v27","v28","vcc"
 // fast class: accumulators (a x 1 + 0: the values never move), multiplicands v24 = 1.0 (bank 0), v25 = 0.0 (bank 1), accumulators in
@@ -2783,20 +2797,20 @@ hipError_t dvo_launch_finish(const DvoPairState* st, int n_pairs, double* xi_out
 #define VR_R16(x) VR_R8(x) VR_R8(x)
 // Mode 0 arranges the composition the way the compiled loop is arranged (tools/isa_count.py prints the class sequence): per point a
 // cluster of conversion-class instructions (the texel unpack), then the FMAs with the bank-conflicted ones among them, the reciprocals
-// in between.  One point: 34 slow, 86 fast, 15 (16) conflict, 2 rcp; a trip = four points = 344 fast, 61 conflict, 136 slow, 8 rcp.
-#define VR_SLOW34 VR_R8(VR_SLOW4A) "v_cvt_f32_i32 v16, v26\n v_cvt_f32_i32 v17, v26\n"
+// in between.  One point: 32 slow, 85 fast, 16 conflict, 2 rcp; a trip = four points (+ one more slow-class instruction: the record
+// registers' hand-over is four 64-bit moves per trip, counted with the points' 32) = 340 fast, 64 conflict, 129 slow, 8 rcp.
+#define VR_SLOW32 VR_R8(VR_SLOW4A)
 #define VR_FAST80 VR_R4(VR_FAST8A VR_FAST8B) VR_FAST8A VR_FAST8B
-#define VR_CONF15 VR_CONF4 VR_CONF4 VR_CONF4 VR_C(2) VR_C(3) VR_C(6)
-#define VR_POINT_A VR_SLOW34 VR_FAST80 VR_RCP VR_F0(2) VR_F0(3) VR_F0(6) VR_F1(7) VR_F0(10) VR_F0(11) VR_CONF15 VR_RCP
-#define VR_POINT_B VR_POINT_A
-#define VR_POINT_C VR_SLOW34 VR_FAST80 VR_RCP VR_F0(2) VR_F0(3) VR_F0(6) VR_F1(7) VR_F0(10) VR_F0(11) VR_CONF15 VR_C(7) VR_RCP
-#define VR_TRIP VR_POINT_A VR_POINT_B VR_POINT_A VR_POINT_C
-static_assert(4 * 86 == DVO_PROBE_FAST && 3 * 15 + 16 == DVO_PROBE_CONFLICT && 4 * 34 == DVO_PROBE_SLOW && 4 * 2 == DVO_PROBE_RCP,
+#define VR_CONF16 VR_R4(VR_CONF4)
+#define VR_POINT_A VR_SLOW32 VR_FAST80 VR_RCP VR_F0(2) VR_F0(3) VR_F0(6) VR_F1(7) VR_F0(10) VR_CONF16 VR_RCP
+#define VR_POINT_C "v_cvt_f32_i32 v16, v26\n" VR_POINT_A
+#define VR_TRIP VR_POINT_A VR_POINT_A VR_POINT_A VR_POINT_C
+static_assert(4 * 85 == DVO_PROBE_FAST && 4 * 16 == DVO_PROBE_CONFLICT && 4 * 32 + 1 == DVO_PROBE_SLOW && 4 * 2 == DVO_PROBE_RCP,
               "VR_TRIP must issue the composition the DVO_PROBE_* constants name");
 // (mode 5, the same composition in small interleaved blocks: 16 fast + 8 slow + 4 conflict = 28;   16 fast + 1 rcp = 17)
 #define VR_X1 VR_FAST8A VR_SLOW4A VR_FAST8B VR_SLOW4B VR_CONF4
 #define VR_X2 VR_FAST8A VR_FAST8B VR_RCP
-#define VR_TRIP_BLOCKS VR_R8(VR_X1) VR_R4(VR_X1) VR_R2(VR_X1) VR_X1 VR_FAST8A VR_SLOW4A VR_FAST8B VR_SLOW4B VR_C(2) VR_R4(VR_X2) VR_X2 VR_SLOW4A VR_SLOW4B VR_FAST8A VR_RCP VR_RCP VR_RCP
+#define VR_TRIP_BLOCKS VR_R16(VR_X1) VR_R4(VR_X2) VR_X2 VR_F0(2) VR_F0(3) VR_F1(6) VR_F0(7) "v_cvt_f32_i32 v16, v26\n" VR_RCP VR_RCP VR_RCP
 __global__ __launch_bounds__(DVO_BLOCK) void k_valu_rate(int mode, int iterations, float* sink)
 {
     extern __shared__ float vr_lds[];                    // only sized: caps the workgroups per CU

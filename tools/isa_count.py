@@ -97,7 +97,12 @@ def kernel_facts(lib: Path = LIB, kernel: str = KERNEL) -> dict:
     ins, target = disassemble(lib, kernel)
     addr_index = {a: i for i, (a, _, _) in enumerate(ins)}
     # loops: s_cbranch_* / s_branch with a negative offset (simm16 dwords relative to the next instruction)
-    best = None
+    # The record loop is everything between the first target and the last source of the backward branches that stay clear of the
+    # epilogue (no LDS, no float64 instruction: those are the workgroup reduction; backward branches spanning it are block-layout
+    # artefacts or the epilogue's own little loops).  With wave-uniform loop control the compiler places the four in-bounds
+    # (phase B) blocks of a trip out of line, behind the loop's own back edge, each returning by a backward branch: the hull of
+    # all of them is one trip.
+    spans = []
     for i, (a, mn, ops) in enumerate(ins):
         if mn.startswith("s_cbranch") or mn == "s_branch":
             try:
@@ -109,17 +114,15 @@ def kernel_facts(lib: Path = LIB, kernel: str = KERNEL) -> dict:
             tgt = a + 4 + 4 * off
             if tgt <= a and tgt in addr_index:
                 j = addr_index[tgt]
-                span = ins[j:i + 1]
-                # the record loop has no LDS and no float64 instruction (those are the epilogue's reduction); backward branches that
-                # span the epilogue are block-layout artefacts (exit paths placed after it), not loops over records
-                if any(m2.startswith("ds_") or "f64" in m2 for (_, m2, _) in span):
+                if any(m2.startswith("ds_") or "f64" in m2 for (_, m2, _) in ins[j:i + 1]):
                     continue
-                n_valu = sum(1 for (_, m2, _) in span if m2.startswith("v_"))
-                if best is None or n_valu > best[2]:
-                    best = (j, i, n_valu)
-    if best is None:
+                spans.append((j, i))
+    if not spans:
         raise RuntimeError("no loop found in {}".format(kernel))
-    body = ins[best[0]:best[1] + 1]
+    lo, hi = min(j for j, _ in spans), max(i for _, i in spans)
+    if any(m2.startswith("ds_") or "f64" in m2 for (_, m2, _) in ins[lo:hi + 1]):
+        raise RuntimeError("the record loop of {} could not be told from its epilogue".format(kernel))
+    body = ins[lo:hi + 1]
     cls = {"fast": 0, "fast_bank_conflict": 0, "slow": 0, "trans": 0}
     hist = {}
     n_vmem = n_salu = n_lds = 0
