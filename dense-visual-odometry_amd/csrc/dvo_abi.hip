@@ -209,6 +209,8 @@ void level_geometry(int w, int h, int levels, DvoLevelGeom* g, size_t* total)
         g[l].wmax_f = (float)(lw - 1);
         g[l].hmax_f = (float)(lh - 1);
         g[l].pitch_f = (float)g[l].pitch;
+        g[l].pitch4_f = 4.0f * (float)g[l].pitch;
+        g[l].tap_bias = (4.0 * (double)(lh + 1) * (double)g[l].pitch < 8388608.0) ? 0x4B000000u : 0u;
         g[l].nseg = (lw * lh + DVO_LIST_SEG - 1) / DVO_LIST_SEG;
         g[l].off_gray = off;
         off = align_up(off + (size_t)lw * lh + 64, 256);
@@ -251,6 +253,15 @@ DvoLevelCam level_camera(const dvo_ctx* c, int level)
     volatile float ic = t / k.fx;
     k.ia = ia; k.ib = ib; k.ic = ic; k.id = id; k.ie = ie;
     k.skew0 = (k.s == 0.0f && k.ib == 0.0f) ? 1 : 0;
+    return k;
+}
+
+// ... for the kernels: the fast instantiations (template argument SKEW = false) skip the zero-skew products AND form tap offsets as float
+// bit patterns (dvo_geo), which needs the level's tap_bias; a level without it (4 (h + 1) pitch >= 2^23) takes the general ones
+DvoLevelCam level_camera(const dvo_ctx* c, int level, const DvoLevelGeom& g)
+{
+    DvoLevelCam k = level_camera(c, level);
+    if (g.tap_bias == 0u) k.skew0 = 0;
     return k;
 }
 
@@ -342,7 +353,7 @@ int fill_reduce_params(dvo_ctx* ctx, int level, int n_pairs, int w, int h, DvoRe
     p->slots = ctx->d_slots;
     p->slot_stride = ctx->slot_stride;
     p->g = g[level];
-    p->cam = level_camera(ctx, level);
+    p->cam = level_camera(ctx, level, g[level]);
     p->depth_scale = ctx->depth_scale;
     p->prev_slot = ctx->d_prev;
     p->cur_slot = ctx->d_cur;
@@ -1119,7 +1130,7 @@ int dvo_residuals_jacobian(dvo_ctx* ctx, int level, int prev_slot, int cur_slot,
     p.slots = ctx->d_slots;
     p.slot_stride = ctx->slot_stride;
     p.g = g[level];
-    p.cam = level_camera(ctx, level);
+    p.cam = level_camera(ctx, level, g[level]);
     p.depth_scale = ctx->depth_scale;
     p.prev_slot = prev_slot;
     p.cur_slot = cur_slot;
@@ -1174,9 +1185,11 @@ static int record_solve(dvo_ctx* ctx, const SolveKey& k, const float* d_init)
             sp.level_id[n] = level - n;
             sp.level_iters[n] = k.level_iters[level - n];
             sp.g[n] = g[level - n];
-            sp.cam[n] = level_camera(ctx, level - n);
+            sp.cam[n] = level_camera(ctx, level - n, g[level - n]);
             ++n;
         }
+        for (int i = 1; i < n; ++i)
+            if (!sp.cam[i].skew0) sp.cam[0].skew0 = 0;          // one instantiation serves all the launch's levels (dvo_launch_gn_small reads cam[0])
         if (n > 0) {
             sp.slots = ctx->d_slots;
             sp.slot_stride = ctx->slot_stride;
@@ -1620,7 +1633,7 @@ int dvo_debug_valu_rate(dvo_ctx* ctx, int waves_per_simd, int iterations, int* c
     HIP_TRY(ctx, hipGetDeviceProperties(&prop, ctx->device));
     const int cus = prop.multiProcessorCount;
 #ifdef DVO_EXPERIMENTS
-    const int n_modes = 24;             // (experiment builds: out[6..13] = other orders and the v_rcp placement cases of tools/ubench/probe_orders.py)
+    const int n_modes = 64;             // (experiment builds: out[6..13] = other orders and the v_rcp placement cases of tools/ubench/probe_orders.py)
 #else
     const int n_modes = 6;
 #endif

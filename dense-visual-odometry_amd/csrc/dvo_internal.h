@@ -19,6 +19,9 @@ struct DvoLevelGeom {
     int w, h, pitch, npix;
     float wmax_f, hmax_f, pitch_f;      // (float)(w-1), (float)(h-1), (float)pitch: kernel arguments live in SGPRs and gfx950
                                         // has no scalar int->float conversion
+    float pitch4_f;                     // 4 * pitch (bytes per packed row) as a float
+    unsigned tap_bias;                  // 0x4B000000 where 4 * (h + 1) * pitch < 2^23 (tap byte offsets are then formed as the bit pattern
+                                        // of a float32 in [2^23, 2^24): dvo_geo), else 0 (offsets by conversion and shift)
     int nseg;                           // ceil(npix / 1024): 1024-pixel segments of the valid-point list builder
     size_t off_gray, off_depth, off_packed;
     size_t off_list;                    // valid-point list: one 8-byte DvoPointRec per depth-valid pixel, raster order

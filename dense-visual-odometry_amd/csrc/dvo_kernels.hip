@@ -829,19 +829,33 @@ __device__ __forceinline__ void dvo_geo(const DvoLevelGeom& g, const DvoLevelCam
     if (WARPED) { o.x = xp * rz; o.y = yp * rz; o.z = rz; }      // z slot = 1 / z' (refined reciprocal), used as such by dvo_finish<3>
     else { o.x = xn; o.y = yn; o.z = z; }
     o.uw = uw; o.vw = vw; o.ax = ax; o.ay = ay; o.ok = ok;
-    // tap offset y0 * pitch + x0, formed in float32 (exact: < 2^24) to save a conversion and an integer multiply
-    o.off = ok ? (unsigned)fmaf(vw - ay, g.pitch_f, uw - ax) : 0u;
+    // Tap BYTE offset 4 (y0 pitch + x0), plus g.tap_bias.  Levels with 4 (h + 1) pitch < 2^23 (every level up to 1920 x 1080): formed
+    // in float32 with 2^23 added - every integer in [2^23, 2^24) is a float32, so both FMAs are exact and the BIT PATTERN of the sum is
+    // 0x4B000000 + the offset: no float -> integer conversion and no left shift (both half rate on gfx950, like every v_cvt / v_bfe /
+    // v_lshlrev; v_fma / v_sub / v_lshrrev / v_ashrrev / v_and / v_or are full rate: tools/ubench/probe_orders.py,
+    // profiles/r04_ubench_instruction_rates.txt); dvo_load_taps takes the bias off the (wave-uniform) base address.  Larger levels:
+    // (and any camera with skew) the offset in float32 (exact: < 2^24), converted and shifted.
+    // The fast instantiations (SKEW = false) are launched only for levels that have the bias (level_camera in dvo_abi.hip).
+    if constexpr (!SKEW) {
+        const float c = fmaf(uw - ax, 4.0f, 8388608.0f);
+        o.off = ok ? __float_as_uint(fmaf(vw - ay, g.pitch4_f, c)) : 0x4B000000u;
+    } else {
+        o.off = (ok ? ((unsigned)fmaf(vw - ay, g.pitch_f, uw - ax)) << 2 : 0u) + g.tap_bias;
+    }
 }
+
+// index (pixels) of the first tap in the packed plane, from the biased byte offset
+__device__ __forceinline__ unsigned dvo_tap_index(const DvoLevelGeom& g, const PixelGeo& q) { return (q.off - g.tap_bias) >> 2; }
 
 __device__ __forceinline__ void dvo_load_taps(const DvoLevelGeom& g, const uint32_t* __restrict__ cur,
                                               const PixelGeo& q, PixelTaps& t)
 {
     // 32-bit byte offset from two wave-uniform row bases: the loads take the scalar base + vector offset form, no
     // 64-bit address arithmetic per lane ((h+1)*pitch < 2^24 is checked at dvo_create, so the offset fits)
-    unsigned boff = q.off << 2;
+    unsigned boff = q.off;                // byte offset + g.tap_bias (dvo_geo)
     asm("" : "+v"(boff));                 // keep the offset 32-bit up to the load (else the zero-extension is hoisted)
-    const char* base0 = reinterpret_cast<const char*>(cur);
-    const char* base1 = reinterpret_cast<const char*>(cur + g.pitch);
+    const char* base0 = reinterpret_cast<const char*>(cur) - g.tap_bias;
+    const char* base1 = base0 + 4 * (size_t)g.pitch;
     t.t0 = *reinterpret_cast<const u32x2_a4*>(base0 + boff);
     t.t1 = *reinterpret_cast<const u32x2_a4*>(base1 + boff);
 }
@@ -856,7 +870,7 @@ __device__ __forceinline__ void dvo_geo_v3(const DvoLevelGeom& g, const DvoLevel
                                            int ux, int vy, unsigned d, PixelGeo& o, float* __restrict__ J)
 {
     o.ok = false;
-    o.off = 0u;
+    o.off = g.tap_bias;
     o.x = o.y = o.z = 0.0f;
     o.uw = o.vw = __builtin_nanf("");
     o.ax = o.ay = 0.0f;
@@ -886,7 +900,7 @@ __device__ __forceinline__ void dvo_geo_v3(const DvoLevelGeom& g, const DvoLevel
     const float x0 = floorf(wx), y0 = floorf(wy);
     const bool ok = (x0 >= 0.0f) && (y0 >= 0.0f) && (x0 + 1.0f < (float)g.w) && (y0 + 1.0f < (float)g.h);
     o.uw = wx; o.vw = wy; o.ax = wx - x0; o.ay = wy - y0; o.ok = ok;
-    o.off = ok ? (unsigned)fmaf(y0, (float)g.pitch, x0) : 0u;
+    o.off = (ok ? ((unsigned)fmaf(y0, (float)g.pitch, x0)) << 2 : 0u) + g.tap_bias;
 }
 
 // Phase B: bilinear photometric lookup, residual, 1x6 Jacobian row.
@@ -2759,19 +2773,19 @@ hipError_t dvo_launch_finish(const DvoPairState* st, int n_pairs, double* xi_out
 // wave-instruction at its occupancy.  This kernel measures that cost in the running process, so that bench.py can put the
 // prediction beside the measured launch (roofline.valu_issue).  ALU only, explicit registers, values that stay finite, straight-line
 // code (one backward branch per ~500 instructions).  Four instruction classes:
-//   fast      v_fmac / v_mul / v_add / v_sub / v_and, operands in different VGPR banks
+//   fast      v_fmac / v_mul / v_add / v_sub / v_and (and right shifts, v_or, v_mov_b32, v_add_u32: all full rate), operands in different VGPR banks
 //   conflict  v_fmac whose two multiplicands sit in ONE bank (register number mod 4): +40-60 % (tools/ubench/vgpr_banks.hip); the
 //             compiler does not allocate by bank, so a real kernel has some (tools/isa_count.py counts them)
-//   slow      conversions, bit-field extract, compare, select, v_fract, shift
+//   slow      half rate: conversions, bit-field extract, compare, select, v_fract, LEFT shift, 64-bit move, min / max (tools/isa_count.py: SLOW)
 //   rcp       v_rcp_f32 (quarter rate)
 // mode 0 issues the composition of ONE TRIP of k_reduce<V1, unweighted>'s record loop as tools/isa_count.py reads it off the built
 // library - DVO_PROBE_FAST / _CONFLICT / _SLOW / _RCP below; dvo_debug_valu_rate reports the composition it ran, bench.py compares it
 // with the kernel that was built, tests/test_cabi_symbols.py with profiles/kernel_isa.json - modes 1..4 one class alone, mode 5 the
 // composition again in another order (the order matters by ~8 %: tools/ubench/probe_orders.py).
 // The launch places `waves_per_simd` 256-thread workgroups on every CU (dynamic LDS sized so that no CU takes more).
-#define DVO_PROBE_FAST 340
-#define DVO_PROBE_CONFLICT 64
-#define DVO_PROBE_SLOW 129
+#define DVO_PROBE_FAST 364
+#define DVO_PROBE_CONFLICT 60
+#define DVO_PROBE_SLOW 105
 #define DVO_PROBE_RCP 8
 #define VR_CLOB "v0","v1","v2","v3","v4","v5","v6","v7","v8","v9","v10","v11","v12","v13","v14","v15","v16","v17","v18","v19","v20","v21","v22","v23","v24","v25","v26","v27","v28","vcc"
 // fast class: accumulators (a x 1 + 0: the values never move), multiplicands v24 = 1.0 (bank 0), v25 = 0.0 (bank 1), accumulators in
@@ -2797,20 +2811,21 @@ hipError_t dvo_launch_finish(const DvoPairState* st, int n_pairs, double* xi_out
 #define VR_R16(x) VR_R8(x) VR_R8(x)
 // Mode 0 arranges the composition the way the compiled loop is arranged (tools/isa_count.py prints the class sequence): per point a
 // cluster of conversion-class instructions (the texel unpack), then the FMAs with the bank-conflicted ones among them, the reciprocals
-// in between.  One point: 32 slow, 85 fast, 16 conflict, 2 rcp; a trip = four points (+ one more slow-class instruction: the record
-// registers' hand-over is four 64-bit moves per trip, counted with the points' 32) = 340 fast, 64 conflict, 129 slow, 8 rcp.
-#define VR_SLOW32 VR_R8(VR_SLOW4A)
+// in between.  One point: 26 slow, 91 fast, 15 conflict, 2 rcp; a trip = four points (+ one more slow-class instruction: the record
+// registers' hand-over is four 64-bit moves per trip, counted with the points' 26) = 364 fast, 60 conflict, 105 slow, 8 rcp.
+#define VR_SLOW26 VR_R4(VR_SLOW4A) VR_SLOW4B VR_SLOW4A "v_cvt_f32_i32 v16, v26\n v_cvt_f32_i32 v17, v26\n"
 #define VR_FAST80 VR_R4(VR_FAST8A VR_FAST8B) VR_FAST8A VR_FAST8B
+#define VR_CONF15 VR_CONF4 VR_CONF4 VR_CONF4 VR_C(2) VR_C(3) VR_C(6)
 #define VR_CONF16 VR_R4(VR_CONF4)
-#define VR_POINT_A VR_SLOW32 VR_FAST80 VR_RCP VR_F0(2) VR_F0(3) VR_F0(6) VR_F1(7) VR_F0(10) VR_CONF16 VR_RCP
+#define VR_POINT_A VR_SLOW26 VR_FAST80 VR_RCP VR_F0(2) VR_F0(3) VR_F0(6) VR_F1(7) VR_F0(10) VR_F0(11) VR_F0(14) VR_F0(15) VR_F1(2) VR_F2(3) VR_F0(6) VR_CONF15 VR_RCP
 #define VR_POINT_C "v_cvt_f32_i32 v16, v26\n" VR_POINT_A
 #define VR_TRIP VR_POINT_A VR_POINT_A VR_POINT_A VR_POINT_C
-static_assert(4 * 85 == DVO_PROBE_FAST && 4 * 16 == DVO_PROBE_CONFLICT && 4 * 32 + 1 == DVO_PROBE_SLOW && 4 * 2 == DVO_PROBE_RCP,
+static_assert(4 * 91 == DVO_PROBE_FAST && 4 * 15 == DVO_PROBE_CONFLICT && 4 * 26 + 1 == DVO_PROBE_SLOW && 4 * 2 == DVO_PROBE_RCP,
               "VR_TRIP must issue the composition the DVO_PROBE_* constants name");
 // (mode 5, the same composition in small interleaved blocks: 16 fast + 8 slow + 4 conflict = 28;   16 fast + 1 rcp = 17)
 #define VR_X1 VR_FAST8A VR_SLOW4A VR_FAST8B VR_SLOW4B VR_CONF4
 #define VR_X2 VR_FAST8A VR_FAST8B VR_RCP
-#define VR_TRIP_BLOCKS VR_R16(VR_X1) VR_R4(VR_X2) VR_X2 VR_F0(2) VR_F0(3) VR_F1(6) VR_F0(7) "v_cvt_f32_i32 v16, v26\n" VR_RCP VR_RCP VR_RCP
+#define VR_TRIP_BLOCKS VR_R8(VR_X1) VR_R4(VR_X1) VR_X1 VR_CONF4 VR_CONF4 "v_cvt_f32_i32 v16, v26\n" VR_R4(VR_X2) VR_X2 VR_R4(VR_FAST8A VR_FAST8B) VR_FAST8A VR_F0(2) VR_F0(3) VR_F1(6) VR_F0(7) VR_RCP VR_RCP VR_RCP
 __global__ __launch_bounds__(DVO_BLOCK) void k_valu_rate(int mode, int iterations, float* sink)
 {
     extern __shared__ float vr_lds[];                    // only sized: caps the workgroups per CU
@@ -2872,6 +2887,51 @@ __global__ __launch_bounds__(DVO_BLOCK) void k_valu_rate(int mode, int iteration
         for (int i = 0; i < iterations; ++i) asm volatile(VR_R16(VR_FAST8A VR_FAST8B "v_rcp_f32 v23, v24\n v_nop\n") ::: VR_CLOB);         // v_nop after it
     } else if (mode == 21) {
         for (int i = 0; i < iterations; ++i) asm volatile(VR_R16(VR_FAST8A VR_FAST8B "v_rcp_f32 v23, v24\n v_cvt_f32_i32 v16, v26\n") ::: VR_CLOB);   // ONE slow op after it
+    // 24..32: single instructions of the conversion class, 512 each (which of them are half rate?)
+#define VR_ONE512(x) for (int i = 0; i < iterations; ++i) asm volatile(VR_R16(VR_R8(x x x x)) ::: VR_CLOB)
+    } else if (mode == 24) { VR_ONE512("v_cvt_f32_i32 v16, v26\n");
+    } else if (mode == 25) { VR_ONE512("v_bfe_i32 v17, v26, 8, 12\n");
+    } else if (mode == 26) { VR_ONE512("v_ashrrev_i32 v18, 20, v26\n");
+    } else if (mode == 27) { VR_ONE512("v_cvt_f32_ubyte0 v19, v26\n");
+    } else if (mode == 28) { VR_ONE512("v_and_or_b32 v20, v26, v27, v24\n");
+    } else if (mode == 29) { VR_ONE512("v_bfi_b32 v21, v27, v26, v24\n");
+    } else if (mode == 30) { VR_ONE512("v_lshlrev_b32 v22, 2, v26\n");
+    } else if (mode == 31) { VR_ONE512("v_fract_f32 v19, v24\n");
+    } else if (mode == 32) {
+        for (int i = 0; i < iterations; ++i) asm volatile(VR_R16(VR_R8("v_cmp_le_u32 vcc, v26, v27\n v_cndmask_b32 v20, v26, v27, vcc\n v_cmp_le_u32 vcc, v26, v27\n v_cndmask_b32 v21, v26, v27, vcc\n")) ::: VR_CLOB);
+    // 40..: more single instructions, destinations rotating over v16..v19 (sources the constants v24 = 1.0, v26 = 0x12345, v27 = -1)
+#define VR_ROT512(op, tail) for (int i = 0; i < iterations; ++i) asm volatile(VR_R16(VR_R8(op " v16, " tail "\n" op " v17, " tail "\n" op " v18, " tail "\n" op " v19, " tail "\n")) ::: VR_CLOB)
+    } else if (mode == 40) { VR_ROT512("v_lshlrev_b32", "2, v26");
+    } else if (mode == 41) { VR_ROT512("v_lshrrev_b32", "20, v26");
+    } else if (mode == 42) { VR_ROT512("v_ashrrev_i32", "20, v26");
+    } else if (mode == 43) { VR_ROT512("v_and_b32", "0xfff, v26");
+    } else if (mode == 44) { VR_ROT512("v_and_b32", "v27, v26");
+    } else if (mode == 45) { VR_ROT512("v_or_b32", "v27, v26");
+    } else if (mode == 46) { VR_ROT512("v_mov_b32", "v26");
+    } else if (mode == 47) {
+        for (int i = 0; i < iterations; ++i) asm volatile(VR_R16(VR_R8("v_mov_b64 v[16:17], v[26:27]\n v_mov_b64 v[18:19], v[26:27]\n v_mov_b64 v[20:21], v[26:27]\n v_mov_b64 v[22:23], v[26:27]\n")) ::: VR_CLOB);
+    } else if (mode == 48) { VR_ROT512("v_add_u32", "v27, v26");
+    } else if (mode == 49) { VR_ROT512("v_sub_f32", "v24, v25");
+    } else if (mode == 50) { VR_ROT512("v_mul_f32", "v24, v25");
+    } else if (mode == 51) { VR_ROT512("v_cvt_f32_u32", "v26");
+    } else if (mode == 52) { VR_ROT512("v_cvt_u32_f32", "v24");
+    } else if (mode == 53) { VR_ROT512("v_cvt_f32_ubyte3", "v26");
+    } else if (mode == 54) { VR_ROT512("v_mad_u32_u24", "v26, v26, v27");
+    } else if (mode == 55) { VR_ROT512("v_perm_b32", "v26, v27, v26");
+    } else if (mode == 56) { VR_ROT512("v_max_f32", "v24, v25");
+    } else if (mode == 57) { VR_ROT512("v_med3_f32", "v24, v25, v24");
+    } else if (mode == 58) { VR_ROT512("v_fma_f32", "v24, v25, v24");
+    } else if (mode == 59) { VR_ROT512("v_bfe_u32", "v26, 12, 12");
+    } else if (mode == 60) { VR_ROT512("v_cvt_f32_i32", "v26");
+    } else if (mode == 61) { VR_ROT512("v_fract_f32", "v24");
+    } else if (mode == 62) { VR_ROT512("v_cvt_f32_f16", "v26");
+    } else if (mode == 63) { VR_ROT512("v_cvt_f32_ubyte1", "v26");
+    } else if (mode == 33) {
+        // the trip with the texel unpack done by mask-and-merge into a float (v_and_or_b32 + v_sub_f32, simple class) instead of
+        // bit-field extract + conversion: per point 16 conversion-class instructions become 16 simple ones
+#define VR_UNPACK_T "v_cvt_f32_ubyte0 v16, v26\n v_and_or_b32 v2, v26, v27, v24\n v_sub_f32 v3, v3, v25\n v_and_or_b32 v6, v26, v27, v24\n v_sub_f32 v7, v7, v25\n"
+#define VR_POINT_M VR_R4(VR_UNPACK_T) VR_R2(VR_SLOW4A) "v_cvt_f32_i32 v16, v26\n v_bfe_i32 v17, v26, 8, 12\n v_cvt_f32_ubyte0 v18, v26\n v_fract_f32 v19, v24\n" VR_FAST80 VR_RCP VR_F0(2) VR_F0(3) VR_F0(6) VR_F1(7) VR_F0(10) VR_CONF16 VR_RCP
+        for (int i = 0; i < iterations; ++i) asm volatile(VR_POINT_M VR_POINT_M VR_POINT_M "v_cvt_f32_i32 v16, v26\n" VR_POINT_M ::: VR_CLOB);
 #endif
     } else {
         for (int i = 0; i < iterations; ++i) asm volatile(VR_R16(VR_R8(VR_RCP)) ::: VR_CLOB);                       // 128 rcp
@@ -2886,6 +2946,7 @@ int dvo_valu_rate_instructions(int mode, int* comp4)
 {
     if (comp4) { comp4[0] = DVO_PROBE_FAST; comp4[1] = DVO_PROBE_CONFLICT; comp4[2] = DVO_PROBE_SLOW; comp4[3] = DVO_PROBE_RCP; }
     if (mode == 6 || mode == 22 || mode == 23) return 548;
+    if (mode == 33) return 541;
     if (mode == 7) return 456;
     if (mode == 8 || mode == 9 || mode == 12 || (mode >= 14 && mode <= 19)) return 272;
     if (mode == 20 || mode == 21) return 288;

@@ -26,8 +26,11 @@ KERNEL = "_Z8k_reduceILi0ELi0ELb0ELb0EEv15DvoReduceParams"          # k_reduce<V
 LLVM = Path("/opt/rocm/lib/llvm/bin")
 
 TRANS = ("v_rcp_", "v_rsq_", "v_sqrt_", "v_exp_", "v_log_", "v_sin_", "v_cos_")
-SLOW = ("v_cvt_", "v_bfe_", "v_cmp", "v_cndmask", "v_fract_", "v_lshl", "v_lshr", "v_ashr", "v_floor_", "v_trunc_", "v_rndne_", "v_mad_u", "v_mul_lo", "v_mul_hi",
-        "v_readfirstlane", "v_mov_")
+# half-rate on gfx950 (measured one instruction at a time, tools/ubench/probe_orders.py -> profiles/r04_ubench_instruction_rates.txt: 1.70 ns per
+# wave-instruction per SIMD at 5 waves against 1.02-1.06 for v_fma / v_mul / v_add / v_sub / v_and / v_or / v_mov_b32 / v_add_u32 / v_lshrrev /
+# v_ashrrev): every conversion, bit-field op, compare, select, v_fract, LEFT shift, min / max / med3, v_perm, 64-bit move, three-operand integer op
+SLOW = ("v_cvt_", "v_bfe_", "v_bfi_", "v_cmp", "v_cndmask", "v_fract_", "v_lshl", "v_floor_", "v_trunc_", "v_rndne_", "v_mad_u", "v_mul_lo", "v_mul_hi",
+        "v_readfirstlane", "v_mov_b64", "v_max_", "v_min_", "v_med3_", "v_perm_", "v_and_or_", "v_or3_", "v_add3_")
 
 
 def _tool(name):

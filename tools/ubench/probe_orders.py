@@ -16,7 +16,7 @@ from dvo_amd import _cabi
 with dvo_amd.HipContext(max_w=64, max_h=48, max_levels=1, n_slots=2, max_pairs=1) as ctx:
     lib = _cabi.lib()
     for waves in (4, 5, 8):
-        out = np.zeros(24, dtype=np.float64)
+        out = np.zeros(64, dtype=np.float64)
         comp = np.zeros(4, dtype=np.int32)
         rc = lib.dvo_debug_valu_rate(ctx._h, waves, 4000, comp.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.POINTER(C.c_double)))
         assert rc == 0
@@ -26,10 +26,18 @@ with dvo_amd.HipContext(max_w=64, max_h=48, max_levels=1, n_slots=2, max_pairs=1
                  "256 fast, v_rcp + s_nop then fast", "256 fast + 64 slow, no v_rcp",
                  "256 fast, v_rcp + s_nop 1", "256 fast, v_rcp + s_nop 3", "256 fast, v_rcp + s_nop 7", "256 fast, v_rcp + s_mov", "256 fast, s_nop + v_rcp + s_nop",
                  "256 fast, 8 x (v_rcp v_rcp s_nop)", "256 fast, v_rcp + v_nop", "256 fast, v_rcp + one v_cvt",
-                 "per point, slow spread between the FMAs (4 : 10)", "per point, slow AND conflict FMAs spread"]
-        counts = [549, 512, 512, 512, 128, 549, 548, 456, 272, 272, 336, 336, 272, 320, 272, 272, 272, 272, 272, 272, 288, 288, 548, 548]
+                 "per point, slow spread between the FMAs (4 : 10)", "per point, slow AND conflict FMAs spread",
+                 "v_cvt_f32_i32 alone", "v_bfe_i32 alone", "v_ashrrev_i32 alone", "v_cvt_f32_ubyte0 alone", "v_and_or_b32 alone", "v_bfi_b32 alone", "v_lshlrev_b32 alone",
+                 "v_fract_f32 alone", "v_cmp + v_cndmask alone", "trip with the texel unpack by mask-and-merge (16 slow -> simple per point)",
+                 "-", "-", "-", "-", "-", "-",
+                 "v_lshlrev_b32 (rotating destinations)", "v_lshrrev_b32", "v_ashrrev_i32", "v_and_b32 literal", "v_and_b32", "v_or_b32", "v_mov_b32", "v_mov_b64", "v_add_u32", "v_sub_f32",
+                 "v_mul_f32", "v_cvt_f32_u32", "v_cvt_u32_f32", "v_cvt_f32_ubyte3", "v_mad_u32_u24", "v_perm_b32", "v_max_f32", "v_med3_f32", "v_fma_f32", "v_bfe_u32",
+                 "v_cvt_f32_i32", "v_fract_f32", "v_cvt_f32_f16", "v_cvt_f32_ubyte1"]
+        counts = [549, 512, 512, 512, 128, 549, 548, 456, 272, 272, 336, 336, 272, 320, 272, 272, 272, 272, 272, 272, 288, 288, 548, 548, 512, 512, 512, 512, 512, 512, 512, 512, 512, 541] + [512] * 30
         print("%d waves per SIMD, composition %s" % (waves, list(comp)))
         for n, v, cnt in zip(names, out, counts):
+            if n == "-":
+                continue
             print("    %-52s %.3f ns per wave-instruction per SIMD   (%6.1f ns per iteration of %d)" % (n, v, v * cnt, cnt))
         f, c, s, r = comp
         print("    class-priced sum for the composition: %.3f ns" % ((f * out[1] + c * out[2] + s * out[3] + r * out[4]) / (f + c + s + r)))
