@@ -1633,7 +1633,7 @@ int dvo_debug_valu_rate(dvo_ctx* ctx, int waves_per_simd, int iterations, int* c
     HIP_TRY(ctx, hipGetDeviceProperties(&prop, ctx->device));
     const int cus = prop.multiProcessorCount;
 #ifdef DVO_EXPERIMENTS
-    const int n_modes = 64;             // (experiment builds: out[6..13] = other orders and the v_rcp placement cases of tools/ubench/probe_orders.py)
+    const int n_modes = 72;             // (experiment builds: out[6..13] = other orders and the v_rcp placement cases of tools/ubench/probe_orders.py)
 #else
     const int n_modes = 6;
 #endif

@@ -2926,6 +2926,16 @@ __global__ __launch_bounds__(DVO_BLOCK) void k_valu_rate(int mode, int iteration
     } else if (mode == 61) { VR_ROT512("v_fract_f32", "v24");
     } else if (mode == 62) { VR_ROT512("v_cvt_f32_f16", "v26");
     } else if (mode == 63) { VR_ROT512("v_cvt_f32_ubyte1", "v26");
+    // 64..: squares and same-bank multiplicand pairs in other encodings (accumulators rotate over v2, v3, v6, v7)
+#define VR_ACC512(op, tail) for (int i = 0; i < iterations; ++i) asm volatile(VR_R16(VR_R8(op " v2, " tail "\n" op " v3, " tail "\n" op " v6, " tail "\n" op " v7, " tail "\n")) ::: VR_CLOB)
+    } else if (mode == 64) { VR_ACC512("v_fmac_f32", "v24, v24");
+    } else if (mode == 65) { VR_ACC512("v_fmac_f32_dpp", "v24, v24 quad_perm:[0,1,2,3] row_mask:0xf bank_mask:0xf");
+    } else if (mode == 66) { VR_ROT512("v_mul_f32", "v24, v24");
+    } else if (mode == 67) { VR_ACC512("v_fmac_f32", "v24, v28");
+    } else if (mode == 68) { VR_ACC512("v_fmac_f32_dpp", "v24, v28 quad_perm:[0,1,2,3] row_mask:0xf bank_mask:0xf");
+    } else if (mode == 69) { VR_ACC512("v_fmac_f32", "v24, v25");
+    } else if (mode == 70) { VR_ACC512("v_fmac_f32_dpp", "v24, v25 quad_perm:[0,1,2,3] row_mask:0xf bank_mask:0xf");
+    } else if (mode == 71) { VR_ROT512("v_mul_f32_sdwa", "v24, v24 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:DWORD");
     } else if (mode == 33) {
         // the trip with the texel unpack done by mask-and-merge into a float (v_and_or_b32 + v_sub_f32, simple class) instead of
         // bit-field extract + conversion: per point 16 conversion-class instructions become 16 simple ones

@@ -16,7 +16,7 @@ from dvo_amd import _cabi
 with dvo_amd.HipContext(max_w=64, max_h=48, max_levels=1, n_slots=2, max_pairs=1) as ctx:
     lib = _cabi.lib()
     for waves in (4, 5, 8):
-        out = np.zeros(64, dtype=np.float64)
+        out = np.zeros(72, dtype=np.float64)
         comp = np.zeros(4, dtype=np.int32)
         rc = lib.dvo_debug_valu_rate(ctx._h, waves, 4000, comp.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.POINTER(C.c_double)))
         assert rc == 0
@@ -32,8 +32,10 @@ with dvo_amd.HipContext(max_w=64, max_h=48, max_levels=1, n_slots=2, max_pairs=1
                  "-", "-", "-", "-", "-", "-",
                  "v_lshlrev_b32 (rotating destinations)", "v_lshrrev_b32", "v_ashrrev_i32", "v_and_b32 literal", "v_and_b32", "v_or_b32", "v_mov_b32", "v_mov_b64", "v_add_u32", "v_sub_f32",
                  "v_mul_f32", "v_cvt_f32_u32", "v_cvt_u32_f32", "v_cvt_f32_ubyte3", "v_mad_u32_u24", "v_perm_b32", "v_max_f32", "v_med3_f32", "v_fma_f32", "v_bfe_u32",
-                 "v_cvt_f32_i32", "v_fract_f32", "v_cvt_f32_f16", "v_cvt_f32_ubyte1"]
-        counts = [549, 512, 512, 512, 128, 549, 548, 456, 272, 272, 336, 336, 272, 320, 272, 272, 272, 272, 272, 272, 288, 288, 548, 548, 512, 512, 512, 512, 512, 512, 512, 512, 512, 541] + [512] * 30
+                 "v_cvt_f32_i32", "v_fract_f32", "v_cvt_f32_f16", "v_cvt_f32_ubyte1",
+                 "v_fmac_f32 acc, a, a (square)", "v_fmac_f32_dpp acc, a, a (identity quad_perm)", "v_mul_f32 d, a, a", "v_fmac_f32 acc, a, b (one bank)", "v_fmac_f32_dpp acc, a, b (one bank)",
+                 "v_fmac_f32 acc, a, b (two banks)", "v_fmac_f32_dpp acc, a, b (two banks)", "v_mul_f32_sdwa d, a, a"]
+        counts = [549, 512, 512, 512, 128, 549, 548, 456, 272, 272, 336, 336, 272, 320, 272, 272, 272, 272, 272, 272, 288, 288, 548, 548, 512, 512, 512, 512, 512, 512, 512, 512, 512, 541] + [512] * 38
         counts[0] = counts[5] = int(comp.sum())             # modes 0 and 5 issue the composition the library was built with
         print("%d waves per SIMD, composition %s" % (waves, [int(v) for v in comp]))
         for n, v, cnt in zip(names, out, counts):
