@@ -696,6 +696,38 @@ def test_maximum_image_size_properties():
             assert abs(swr2 - float(r64 @ r64)) < 1e-6 * swr2
 
 
+def test_levels_with_and_without_float_pattern_tap_offsets_vs_oracle():
+    """2048 x 1100: level 0 is past the size up to which tap byte offsets are formed as float32 bit patterns (4 (h + 1) pitch >= 2^23:
+    offsets by conversion and shift, the general instantiations), levels 1 and 2 are below it (the fast ones) - one context, one solve,
+    both kinds of launch.  Each level's validity count and normal equations against the oracle, and the device solve (3 iterations per
+    level) against the oracle's."""
+    import dvo_amd
+    from dvo_amd import _cabi
+    rng = np.random.default_rng(4242)
+    w, h, levels = 2048, 1100, 3
+    img, depth = _synthetic_frame(rng, h, w)
+    img2 = np.roll(img, (1, 2), axis=(0, 1))
+    K = np.array([[1650.0, 0, 1023.5], [0, 1650.0, 549.5], [0, 0, 1]], dtype=np.float32)
+    T = O.Pose.from_xi(np.array([0.002, -0.001, 0.001, 0.001, -0.0005, 0.001])).matrix()
+    with dvo_amd.HipContext(max_w=w, max_h=h, max_levels=levels, n_slots=2, max_pairs=1) as ctx:
+        ctx.set_camera(K[0, 0], K[1, 1], K[0, 2], K[1, 2], 0.0, 0.0002)
+        ctx.upload_frame(0, img, depth, levels)
+        ctx.upload_frame(1, img2, depth, levels)
+        pg1, pd1 = O.build_pyramid(img, levels), O.build_pyramid(depth, levels)
+        pg2 = O.build_pyramid(img2, levels)
+        for lvl in range(levels):
+            lv = O.PairLevel(pg1[lvl], pd1[lvl], pg2[lvl], O.level_intrinsics(K, lvl), 0.0002)
+            ro, Jo, _, valid_o = O.residuals_and_jacobian(lv, T, "v1")
+            Ho, bo, so, no = O.normal_equations(ro, Jo)
+            H, b, swr2, n, sr2 = _cabi.unpack_record(ctx.normal_equations(lvl, [0], [1], T[None])[0])
+            assert n == no == int(valid_o.sum()), lvl
+            assert _rel(H, Ho) < 1e-5 and _rel(b, bo) < 1e-4 and abs(swr2 - so) <= 1e-5 * so, lvl
+        dev = ctx.solve_batch([0], [1], levels=levels, max_iterations=3)
+    est = O.gauss_newton(img, depth, img2, K, 0.0002, levels, max_iterations=3)
+    assert int(dev["iters"][0]) == 3 * levels
+    np.testing.assert_allclose(dev["xi"][0], est.log(), rtol=0, atol=1e-4 * np.abs(est.log()).max())       # (3e-6 on the fixture pairs is 3e-4 of their xi)
+
+
 def test_projection_division_is_bit_identical_to_ieee(hip):
     """The projection's quotient (shared refined reciprocal + ONE residual correction, no v_div_scale / v_div_fixup) against the
     compiler's IEEE division on the device and against NumPy, over the operand ranges the projection sees."""
