@@ -1160,9 +1160,9 @@ __global__ __launch_bounds__(DVO_BLOCK, (VARIANT == 2) ? 2 : DVO_REDUCE_WAVES_PE
     const int g_lo = (blk * ngroups) / p.blocks_per_pair, g_hi = ((blk + 1) * ngroups) / p.blocks_per_pair;
     const int wave_off = wave_ * (64 * DVO_PX_PER_THREAD);                            // wave-uniform
     const int rec0 = g_lo * DVO_PX_PER_BLOCK + wave_off;
-    // the records of the next group are requested one group ahead, so their latency is covered by the arithmetic of
-    // the current group and only the dependent tap gathers are waited for
-    unsigned long long rn[DVO_PX_PER_THREAD];     // 64-bit values: the loop-carried registers ARE the loads' destination pairs
+    // The records of a group are requested during the group before it (behind that group's tap gathers, see the loop), the first ones here.
+    // Held as 64-bit values: the loop-carried registers are the loads' own destination pairs.
+    unsigned long long rn[DVO_PX_PER_THREAD];
 #pragma unroll
     for (int j = 0; j < DVO_PX_PER_THREAD; ++j) rn[j] = 0ull;
     const bool nt_records = p.nt_records != 0;                            // launch-uniform
@@ -1181,7 +1181,8 @@ __global__ __launch_bounds__(DVO_BLOCK, (VARIANT == 2) ? 2 : DVO_REDUCE_WAVES_PE
         // phase A for all pixels of the lane, then all tap loads back to back (memory-level parallelism: the
         // dependent gathers of 4 pixels are in flight together), then the request for the next group's records, then phase B.
         // Phase A takes everything it needs out of the records (the previous frame's intensity as a float), so the next
-        // group's records are loaded into the SAME registers: no rotation of a current / next pair (8 v_mov_b64 per trip).
+        // group's records are loaded over them: no current / next pair of register sets to rotate (that cost 8 v_mov_b64 per trip;
+        // 4 are left, the allocator's own split of the range).
         PixelGeo geo[DVO_PX_PER_THREAD];
         PixelTaps taps[DVO_PX_PER_THREAD];
         float i1f[DVO_PX_PER_THREAD];
