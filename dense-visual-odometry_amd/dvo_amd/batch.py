@@ -168,6 +168,32 @@ class StreamedAligner:
         res = [a.solve_fetch(hi - lo + 1) for a, lo, hi in sl]
         return {k: np.concatenate([r[k] for r in res], axis=0) for k in res[0]}
 
+    def submit_host(self, img: np.ndarray, depth: np.ndarray, colour: bool = False, max_distance: float = 5.0):
+        """Pipelined form of align_host / align_host_bgr for a stream of windows in (page-locked) host memory, as submit_device: slice
+        by slice, the result of the slice's previous window is fetched and its next window (upload + ingest + solve) enqueued right
+        behind it.  The arrays must stay valid until the NEXT submit_host / drain has returned (their uploads are asynchronous).
+        A window of another size than the one in flight is preceded by a drain.  Returns the previous window's result (None for the
+        first call); drain() returns the last one."""
+        n_frames = img.shape[0]
+        sl = self._slices(n_frames)
+        prev = self._inflight
+        drained = None
+        if prev is not None and [(lo, hi) for _, lo, hi in prev] != [(lo, hi) for _, lo, hi in sl]:
+            drained, prev = self.drain(), None
+        res = []
+        for a, lo, hi in sl:
+            if prev is not None:
+                res.append(a.solve_fetch(hi - lo + 1))
+            if colour:
+                a.ingest_host_bgr(img[lo:hi + 1], depth[lo:hi + 1], max_distance)
+            else:
+                a.ingest_host(img[lo:hi + 1], depth[lo:hi + 1])
+            a.solve_enqueue(hi - lo + 1)
+        self._inflight = sl
+        if drained is not None:
+            return drained
+        return {k: np.concatenate([r[k] for r in res], axis=0) for k in res[0]} if res else None
+
     def align_host(self, gray: np.ndarray, depth: np.ndarray):
         """Host frames [n][h][w] (ideally page-locked): the H2D copy of one slice overlaps the solve of another."""
         n_frames = gray.shape[0]

@@ -113,7 +113,14 @@ class DecoderPool:
             if yielded == submitted:
                 if exhausted:
                     return
-                raise RuntimeError("DecoderPool: every slot is held by the consumer (release a Decoded before asking for the next)")
+                # every slot is with the consumer: it may still be copying the frames out in other threads (FrameWindows does) - wait for
+                # a release; a consumer that never releases is an error
+                t_wait = time.monotonic()
+                while not free:
+                    if time.monotonic() - t_wait > 30.0:
+                        raise RuntimeError("DecoderPool: every slot is held by the consumer (release a Decoded before asking for the next)")
+                    time.sleep(0.0002)
+                continue
             while yielded not in ready:
                 g, tid, slot, err = self._results.get()
                 if g == gen:
@@ -164,7 +171,8 @@ class FrameWindows:
     iteration is (image_window, depth_window, n_frames_in_window): views into a ring slot that stay valid until `depth`
     further windows have been requested (`ring` = 3 by default: one being aligned, one uploaded, one being filled)."""
 
-    def __init__(self, frames: Iterable, window_pairs: int, alloc: Callable = None, ring: int = 3, workers=0):
+    def __init__(self, frames: Iterable, window_pairs: int, alloc: Callable = None, ring: int = 3, workers=0, copy_threads: int = 4,
+                 buffers: Optional[List[Tuple[np.ndarray, np.ndarray]]] = None):
         """`frames` may also yield zero-argument callables returning (image, depth) — e.g. PNG decoders; with `workers` > 0
         they run in a pool of that many threads (PIL releases the GIL while inflating), with `workers` a DecoderPool in its worker
         processes; results are kept in sequence order either way."""
@@ -178,10 +186,20 @@ class FrameWindows:
         self._free: "queue.Queue" = queue.Queue()
         self._err: Optional[BaseException] = None
         self._thread = threading.Thread(target=self._fill, name="dvo-frame-decoder", daemon=True)
-        self._bufs: List[Tuple[np.ndarray, np.ndarray]] = []
+        # `buffers`: the ring of another FrameWindows of the same geometry (its `.buffers` once it has run) - page-locking a ring of three
+        # 129-frame VGA colour windows (600 MB) takes ~0.1 s, which a caller that walks many short sequences need not pay each time
+        self._bufs: List[Tuple[np.ndarray, np.ndarray]] = list(buffers) if buffers else []
+        if self._bufs:
+            if len(self._bufs) != ring or any(b[0].shape[0] != window_pairs + 1 or b[1].shape[0] != window_pairs + 1 for b in self._bufs):
+                raise ValueError("buffers must be {} (image, depth) windows of {} frames".format(ring, window_pairs + 1))
+            for i in range(ring):
+                self._free.put(i)
         self._started = False
         self._stop = False
         self.decode_seconds = 0.0
+        # frames are copied into the window by a few threads (NumPy releases the GIL for the copy): one thread moves ~19 k VGA colour
+        # frames/s on the GPU box's host, four ~28 k (tools/ubench/copy_rate.py) - one is not enough beside a device that aligns 30 k
+        self._copy_threads = max(0, int(copy_threads))
 
     @staticmethod
     def _resolve(it, workers):
@@ -205,6 +223,11 @@ class FrameWindows:
                 head = pending.popleft()
                 yield head.result() if hasattr(head, "result") else head
 
+    @property
+    def buffers(self) -> List[Tuple[np.ndarray, np.ndarray]]:
+        """The ring's window arrays (empty until the first frame has arrived), for reuse by a later FrameWindows."""
+        return self._bufs
+
     def _make_buffers(self, img, depth):
         shape = (self._w + 1,) + tuple(img.shape)
         for _ in range(self._ring):
@@ -222,13 +245,25 @@ class FrameWindows:
                 continue
         return False
 
+    @staticmethod
+    def _copy_in(ib, db, k, img, dep, release):
+        ib[k] = img
+        db[k] = dep
+        if release is not None:
+            release()
+
     def _fill(self):
+        pool = None
+        if self._copy_threads > 1:
+            from concurrent.futures import ThreadPoolExecutor
+            pool = ThreadPoolExecutor(max_workers=self._copy_threads, thread_name_prefix="dvo-copy")
         try:
             carry = None
             done = False
             while not done and not self._stop:
                 t0 = time.perf_counter()
                 slot, k, ib, db = None, 0, None, None
+                copies = []
                 while k < self._w + 1:
                     release = None
                     if carry is not None:
@@ -256,11 +291,14 @@ class FrameWindows:
                     if img.shape != ib.shape[1:] or dep.shape != db.shape[1:]:
                         raise ValueError("frame {} of the window has shape {} / {}, expected {} / {}".format(
                             k, img.shape, dep.shape, ib.shape[1:], db.shape[1:]))
-                    ib[k] = img                                 # frames go into the (page-locked) window as they arrive
-                    db[k] = dep
-                    if release is not None:
-                        release()
+                    # frames go into the (page-locked) window as they arrive
+                    if pool is not None:
+                        copies.append(pool.submit(self._copy_in, ib, db, k, img, dep, release))
+                    else:
+                        self._copy_in(ib, db, k, img, dep, release)
                     k += 1
+                for c in copies:
+                    c.result()
                 if k < 2:
                     break
                 carry = (ib[k - 1].copy(), db[k - 1].copy())     # the next window may land in another slot
@@ -270,6 +308,8 @@ class FrameWindows:
         except BaseException as e:                  # surfaced in the consumer thread
             self._err = e
         finally:
+            if pool is not None:
+                pool.shutdown(wait=True)
             self._put(None)
 
     def __iter__(self) -> Iterator[Tuple[np.ndarray, np.ndarray, int]]:
@@ -302,14 +342,25 @@ def align_windows(aligner, windows: Iterable[Tuple[np.ndarray, np.ndarray, int]]
     -> dict(T (n_pairs,3,4), iters, err, seconds)"""
     T, iters, errs = [], [], []
     t0 = time.perf_counter()
-    for img, dep, n in windows:
-        if colour:
-            res = aligner.align_host_bgr(img, dep, max_distance) if hasattr(aligner, "align_host_bgr") else _align_bgr(aligner, img, dep, max_distance)
-        else:
-            res = aligner.align_host(img, dep)
-        T.append(res["T"])
-        iters.append(res["iters"])
-        errs.append(res["err"])
+
+    def keep(res):
+        if res is not None:
+            T.append(res["T"])
+            iters.append(res["iters"])
+            errs.append(res["err"])
+
+    if hasattr(aligner, "submit_host"):
+        # windows pipelined through the slices (StreamedAligner.submit_host): the GPU does not drain between windows, and the host
+        # collects window k's results while window k + 1 is uploading.  A FrameWindows ring of 3 keeps the window in flight valid.
+        for img, dep, n in windows:
+            keep(aligner.submit_host(img, dep, colour, max_distance))
+        keep(aligner.drain())
+    else:
+        for img, dep, n in windows:
+            if colour:
+                keep(aligner.align_host_bgr(img, dep, max_distance) if hasattr(aligner, "align_host_bgr") else _align_bgr(aligner, img, dep, max_distance))
+            else:
+                keep(aligner.align_host(img, dep))
     return {"T": np.concatenate(T) if T else np.zeros((0, 3, 4), np.float32),
             "iters": np.concatenate(iters) if iters else np.zeros(0, np.int32),
             "err": np.concatenate(errs) if errs else np.zeros(0), "seconds": time.perf_counter() - t0}

@@ -435,6 +435,35 @@ def test_pipelined_windows_equal_window_by_window_alignment(vga_stream):
         al.close()
 
 
+@pytest.mark.parametrize("colour", [False, True])
+def test_pipelined_host_windows_equal_window_by_window_alignment(vga_stream, colour):
+    """sequence.align_windows over a StreamedAligner (submit_host / drain: windows of page-locked host frames pipelined through the
+    slices, a shorter last window preceded by a drain inside submit_host) returns, in sequence order, exactly what aligning every
+    window by itself returns; frames copied into the ring by several threads."""
+    from dvo_amd import _cabi, sequence
+    from dvo_amd.batch import StreamedAligner
+    st = vga_stream
+    n, win = 9, 3
+    assert st["gray"].shape[0] >= n
+    gray, depth = st["gray"][:n], st["depth"][:n]
+    img = np.repeat(gray[..., None], 3, axis=3) if colour else gray
+    al = StreamedAligner(st["K"], st["depth_scale"], 640, 480, 4, max_pairs=win, n_streams=2, max_iterations=3)
+    try:
+        want = {"T": [], "iters": [], "err": []}
+        for lo in range(0, n - 1, win):                                 # windows of 3 pairs: frames [0..3], [3..6], [6..8]
+            hi = min(lo + win, n - 1)
+            r = al.align_host_bgr(np.ascontiguousarray(img[lo:hi + 1]), depth[lo:hi + 1]) if colour else al.align_host(gray[lo:hi + 1], depth[lo:hi + 1])
+            for k in want:
+                want[k].append(r[k])
+        fw = sequence.FrameWindows(((img[k], depth[k]) for k in range(n)), win, alloc=_cabi.pinned_array, copy_threads=3)
+        got = sequence.align_windows(al, fw, colour)
+        assert got["T"].shape[0] == n - 1
+        for k in want:
+            assert np.array_equal(np.concatenate(want[k]), got[k]), k
+    finally:
+        al.close()
+
+
 def test_rccl_pose_gather_through_the_c_abi():
     """dvo_comm_* (RCCL via dlopen): world of one rank on the test box — unique id, communicator, all-gather."""
     from dvo_amd import _cabi

@@ -26,6 +26,53 @@ def test_frame_windows_cover_every_pair_once(n, window):
     assert seen == [(a, a + 1) for a in range(n - 1)]          # consecutive windows share exactly one frame
 
 
+@pytest.mark.parametrize("copy_threads", [0, 1, 4])
+def test_frame_windows_copy_threads_and_ring_reuse(copy_threads):
+    """Frames copied into the windows by a pool of threads land where the inline copy puts them; the ring of one FrameWindows can be
+    handed to the next (page-locking a ring is a start-up cost), and a ring of another geometry is refused."""
+    first = sequence.FrameWindows(_frames(11), 4, copy_threads=copy_threads)
+    a = [(img.copy(), dep.copy(), m) for img, dep, m in first]
+    assert len(first.buffers) == 3
+    second = sequence.FrameWindows(_frames(11), 4, copy_threads=copy_threads, buffers=first.buffers)
+    b = [(img.copy(), dep.copy(), m) for img, dep, m in second]
+    assert second.buffers[0][0] is first.buffers[0][0]
+    ref = [(img.copy(), dep.copy(), m) for img, dep, m in sequence.FrameWindows(_frames(11), 4, copy_threads=0)]
+    for got in (a, b):
+        assert len(got) == len(ref)
+        for (i1, d1, m1), (i2, d2, m2) in zip(got, ref):
+            assert m1 == m2 and np.array_equal(i1, i2) and np.array_equal(d1, d2)
+    with pytest.raises(ValueError):
+        sequence.FrameWindows(_frames(11), 5, buffers=first.buffers)
+
+
+def test_align_windows_pipelines_through_submit_host():
+    """An aligner with submit_host / drain (StreamedAligner) gets the windows pipelined: every window submitted once, results in
+    sequence order, the last one drained; a window of another size arrives as it is (the aligner drains by itself)."""
+    class Stub:
+        def __init__(self):
+            self.calls, self.inflight = [], None
+
+        def _result(self, img):
+            n = img.shape[0] - 1
+            ids = img[:-1, 0, 0].astype(np.int32)
+            return {"T": np.tile(np.eye(4, dtype=np.float32)[:3], (n, 1, 1)) * ids[:, None, None], "iters": ids, "err": ids.astype(np.float64)}
+
+        def submit_host(self, img, dep, colour, max_distance):
+            self.calls.append(("submit", img.shape[0]))
+            prev, self.inflight = self.inflight, self._result(img)          # (computed at submit: the ring may recycle `img` later)
+            return prev
+
+        def drain(self):
+            self.calls.append(("drain",))
+            prev, self.inflight = self.inflight, None
+            return prev
+
+    al = Stub()
+    res = sequence.align_windows(al, sequence.FrameWindows(_frames(11), 4), colour=False)
+    assert al.calls == [("submit", 5), ("submit", 5), ("submit", 3), ("drain",)]
+    assert list(res["iters"]) == list(range(10)) and res["T"].shape == (10, 3, 4)
+
+
 def test_frame_windows_with_a_decoder_pool_keeps_the_order():
     import time
 

@@ -52,17 +52,21 @@ def measure(n_frames=480, n_distinct=48, threads=(8, 16), window=128, streams=2,
         al = StreamedAligner(st["K"], st["depth_scale"], W, H, levels, max_pairs=window, n_streams=streams, device=device, max_iterations=iterations)
         try:
             # warm-up: graphs captured, page cache warm
-            sequence.align_windows(al, sequence.FrameWindows(list(thunks())[:window + 1], window, alloc=_cabi.pinned_array, workers=max(threads)), colour)
+            # one ring of page-locked windows for every measurement below (page-locking 3 x 129 VGA colour frames takes ~0.1 s: a start-up
+            # cost of a run, not part of its rate)
+            warm = sequence.FrameWindows(list(thunks())[:window + 1], window, alloc=_cabi.pinned_array, workers=max(threads))
+            sequence.align_windows(al, warm, colour)
+            ring = warm.buffers
             rows = []
             for w in list(threads) + list(pools):
                 is_pool = not isinstance(w, int)
                 row = {"decoder_processes": len(w._procs)} if is_pool else {"decoder_threads": w}
                 if decode_only:
                     t0 = time.perf_counter()
-                    fw = sequence.FrameWindows(thunks(), window, alloc=_cabi.pinned_array, workers=w)
+                    fw = sequence.FrameWindows(thunks(), window, workers=w, buffers=ring)
                     cnt = sum(k - 1 for _, _, k in fw) + 1
                     row["decode_only_frames_per_s"] = cnt / (time.perf_counter() - t0)
-                fw = sequence.FrameWindows(thunks(), window, alloc=_cabi.pinned_array, workers=w)
+                fw = sequence.FrameWindows(thunks(), window, workers=w, buffers=ring)
                 res = sequence.align_windows(al, fw, colour)
                 row["frame_pairs_per_s"] = res["T"].shape[0] / res["seconds"]
                 row["decoder_thread_busy_s"] = fw.decode_seconds
@@ -76,11 +80,13 @@ def measure(n_frames=480, n_distinct=48, threads=(8, 16), window=128, streams=2,
                 frames = [(_read if colour else _read_gray)(seq.rgb_paths[k], seq.depth_paths[k]) for k in range(min(n, n_distinct))]
                 period = max(2 * (len(frames) - 1), 1)
                 idx = [(i % period) if (i % period) < len(frames) else period - (i % period) for i in range(n)]
-                fw = sequence.FrameWindows((frames[i] for i in idx), window, alloc=_cabi.pinned_array)
+                fw = sequence.FrameWindows((frames[i] for i in idx), window, buffers=ring)
                 res = sequence.align_windows(al, fw, colour)
                 out["from_memory_frame_pairs_per_s"] = res["T"].shape[0] / res["seconds"]
+                out["from_memory_fill_thread_busy_s"] = fw.decode_seconds
                 if log:
-                    log("  decoded frames in memory (memcpy into the windows): %7.0f frame-pairs/s" % out["from_memory_frame_pairs_per_s"])
+                    log("  decoded frames in memory (memcpy into the windows): %7.0f frame-pairs/s  (fill thread busy %.0f of %.0f ms)" % (
+                        out["from_memory_frame_pairs_per_s"], 1e3 * fw.decode_seconds, 1e3 * res["seconds"]))
         finally:
             al.close()
     best = max(out["by_decoder_threads"], key=lambda r: r["frame_pairs_per_s"])
