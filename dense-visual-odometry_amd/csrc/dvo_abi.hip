@@ -156,7 +156,9 @@ struct dvo_ctx {
     // solve graph bakes them in, so they must not change under it)
     struct Knobs {
         int xcd_remap = 0;          // DVO_XCD_REMAP=1: XCD-aware logical block order (measured slower)
-        int max_groups = 16;        // DVO_MAX_GROUPS
+        int max_groups = 48;        // DVO_MAX_GROUPS: record groups (1024 records) per reduction workgroup at most.  In the job 48 beats 16 by 1.0-1.3 %
+                                    // (tools/exp_max_groups.sh, profiles/r04_experiments.txt [9]): each workgroup pays its prologue and its
+                                    // 30-term float64 reduction once, and with four streams in flight nobody waits for a launch's tail
         int target_blocks = 1024;   // DVO_TARGET_BLOCKS
         bool st_solve_phases = false;   // DVO_ST_SOLVE_PHASES: Student-t device solve with control launches between the passes
         bool no_rcache = false;         // DVO_NO_RCACHE: second Student-t scale pass recomputes the residuals

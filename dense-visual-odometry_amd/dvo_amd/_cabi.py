@@ -472,7 +472,7 @@ class HipContext:
         """ns per VALU wave-instruction per SIMD at `waves_per_simd` resident waves: for the composition of one trip of the level-0
         reduction's record loop ("composition": simple, simple with a VGPR bank conflict, conversion-class, v_rcp_f32 instructions)
         and for each class alone."""
-        out = np.zeros(8, dtype=np.float64)
+        out = np.zeros(128, dtype=np.float64)       # the product library writes 6 values; an experiments build (DVO_HIP_LIB) one per probe mode
         comp = np.zeros(4, dtype=np.int32)
         self._check(self._lib.dvo_debug_valu_rate(self._h, waves_per_simd, iterations, _ptr(comp), out.ctypes.data_as(_c_double_p)))
         f, c, s, r = (int(v) for v in comp)

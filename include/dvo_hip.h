@@ -293,7 +293,7 @@ int dvo_profile_read(dvo_ctx* ctx, int64_t* launches, double* ms, int reset);
  * each class alone; out[5]: the composition again, interleaved in small blocks (the order of the classes matters by ~8 %).  ALU-only
  * launches of `iterations` x ~500 instructions per wave.  bench.py multiplies out[0] by the kernel's instruction count to put the
  * issue-bound prediction beside the measured launch time (roofline.valu_issue). */
-int dvo_debug_valu_rate(dvo_ctx* ctx, int waves_per_simd, int iterations, int* composition /* [4] or NULL */, double* ns_per_wave_instr /* [8] */);
+int dvo_debug_valu_rate(dvo_ctx* ctx, int waves_per_simd, int iterations, int* composition /* [4] or NULL */, double* ns_per_wave_instr /* [8]; an experiments build writes one value per probe mode: [128] */);
 /* Event-pair stopwatch on the ctx stream. */
 int dvo_timer_start(dvo_ctx* ctx);
 int dvo_timer_stop(dvo_ctx* ctx, float* ms);
