@@ -728,6 +728,7 @@ struct PixelGeo {
     float ax, ay;        // their fractional parts uw - floor(uw), vw - floor(vw) (exact)
     unsigned off;        // offset of tap (y0, x0) in the packed plane (0 when !ok, so the load is harmless)
     bool ok;             // depth != 0 && warped point inside the closed image rectangle
+    int n_ok;            // ... how many lanes of the wave have it (dvo_geo only; wave-uniform)
 };
 
 struct __attribute__((packed, aligned(4))) u32x2_a4 { uint32_t a, b; };
@@ -829,6 +830,9 @@ __device__ __forceinline__ void dvo_geo(const DvoLevelGeom& g, const DvoLevelCam
     if (WARPED) { o.x = xp * rz; o.y = yp * rz; o.z = rz; }      // z slot = 1 / z' (refined reciprocal), used as such by dvo_finish<3>
     else { o.x = xn; o.y = yn; o.z = z; }
     o.uw = uw; o.vw = vw; o.ax = ax; o.ay = ay; o.ok = ok;
+    // (s_bcnt1 of the compares' own result masks; a ballot of the combined flag would have it materialised in a VGPR first)
+    o.n_ok = __builtin_popcountll(__builtin_amdgcn_ballot_w64(__float_as_uint(uw) <= __float_as_uint(g.wmax_f)) &
+                                  __builtin_amdgcn_ballot_w64(__float_as_uint(vw) <= __float_as_uint(g.hmax_f)) & __builtin_amdgcn_ballot_w64(live));
     // Tap BYTE offset 4 (y0 pitch + x0), plus g.tap_bias.  Levels with 4 (h + 1) pitch < 2^23 (every level up to 1920 x 1080): formed
     // in float32 with 2^23 added - every integer in [2^23, 2^24) is a float32, so both FMAs are exact and the BIT PATTERN of the sum is
     // 0x4B000000 + the offset: no float -> integer conversion and no left shift (both half rate on gfx950, like every v_cvt / v_bfe /
@@ -1175,6 +1179,9 @@ __global__ __launch_bounds__(DVO_BLOCK, (VARIANT == 2) ? 2 : DVO_REDUCE_WAVES_PE
             for (int j = 0; j < DVO_PX_PER_THREAD; ++j) rn[j] = dvo_rec_load64<false>(reinterpret_cast<const unsigned long long*>(list + rec0 + j * 64 + lane_));
         }
     }
+    // the number of valid points is counted per WAVE from the in-bounds lane masks (s_bcnt1 on the compare's result: scalar unit) instead of
+    // one v_add per lane and point; lane 0 hands it to the reduction after the loop
+    int n_ok = 0;
     for (int grp = g_lo; grp < g_hi; ++grp) {
         const int seg = grp * DVO_PX_PER_BLOCK + wave_off;
         if (seg >= count) break;                                          // wave-uniform
@@ -1228,6 +1235,8 @@ __global__ __launch_bounds__(DVO_BLOCK, (VARIANT == 2) ? 2 : DVO_REDUCE_WAVES_PE
         }
 #pragma unroll
         for (int j = 0; j < DVO_PX_PER_THREAD; ++j) {
+            if constexpr (VARIANT == 2) n_ok += __builtin_popcountll(__builtin_amdgcn_ballot_w64(geo[j].ok));     // (dvo_geo_v3 does not count)
+            else n_ok += geo[j].n_ok;
             if (geo[j].ok) {                                  // depth != 0 (camera_model.py:195) and in bounds
                 PixelOut o;
                 dvo_finish<VARIANT, !SCALE_PASS>(cam, geo[j], taps[j], i1f[j], o);
@@ -1240,7 +1249,6 @@ __global__ __launch_bounds__(DVO_BLOCK, (VARIANT == 2) ? 2 : DVO_REDUCE_WAVES_PE
                 if constexpr (SCALE_PASS) {
                     // r^2 * (dof+1)/(dof + r^2*lambda), dof = 5 (weighter/t_weighter.py:43-45)
                     acc[0] += r2 * (6.0f * fast_rcp(fmaf(r2, wpar, 5.0f)));
-                    acc[1] += 1.0f;
                     rkeep[j] = r;
                 } else {
                     float wt = 1.0f;
@@ -1257,7 +1265,6 @@ __global__ __launch_bounds__(DVO_BLOCK, (VARIANT == 2) ? 2 : DVO_REDUCE_WAVES_PE
 #pragma unroll
                     for (int k = 0; k < 6; ++k) acc[21 + k] = fmaf(wj[k], r, acc[21 + k]);
                     if (WMODE != 5) acc[27] = fmaf((WMODE == 0 || WMODE == 4) ? r : wt * r, r, acc[27]);   // (4: the plain moment sum r^2)
-                    acc[28] += 1.0f;
                     if (WMODE == 1 || WMODE == 2 || WMODE == 5) acc[29] += r2;             // WMODE 0: copied from acc[27] after the loop
                     if constexpr (WMODE == 5) {
                         // beside the system weighted with the predicted lambda: the first scale pass under the constant lambda0
@@ -1308,6 +1315,7 @@ __global__ __launch_bounds__(DVO_BLOCK, (VARIANT == 2) ? 2 : DVO_REDUCE_WAVES_PE
         }
     }
 
+    acc[SCALE_PASS ? 1 : 28] = (lane_ == 0) ? (float)n_ok : 0.0f;               // (a wave counts at most 2^24 points: exact)
     if constexpr (!SCALE_PASS && WMODE == 0) acc[NACC - 1] = acc[NACC - 3];     // sum r^2 == sum w r^2 when w == 1
     // Workgroup reduction.  float32 only inside one lane; everything across lanes / waves / workgroups is float64.
     // The 30 per-lane sums are transposed through LDS instead of 30 x 6 cross-lane butterflies: every lane stores
@@ -2784,9 +2792,9 @@ hipError_t dvo_launch_finish(const DvoPairState* st, int n_pairs, double* xi_out
 // with the kernel that was built, tests/test_cabi_symbols.py with profiles/kernel_isa.json - modes 1..4 one class alone, mode 5 the
 // composition again in another order (the order matters by ~8 %: tools/ubench/probe_orders.py).
 // The launch places `waves_per_simd` 256-thread workgroups on every CU (dynamic LDS sized so that no CU takes more).
-#define DVO_PROBE_FAST 364
+#define DVO_PROBE_FAST 360
 #define DVO_PROBE_CONFLICT 60
-#define DVO_PROBE_SLOW 105
+#define DVO_PROBE_SLOW 109
 #define DVO_PROBE_RCP 8
 #define VR_CLOB "v0","v1","v2","v3","v4","v5","v6","v7","v8","v9","v10","v11","v12","v13","v14","v15","v16","v17","v18","v19","v20","v21","v22","v23","v24","v25","v26","v27","v28","vcc"
 // fast class: accumulators (a x 1 + 0: the values never move), multiplicands v24 = 1.0 (bank 0), v25 = 0.0 (bank 1), accumulators in
@@ -2812,21 +2820,22 @@ hipError_t dvo_launch_finish(const DvoPairState* st, int n_pairs, double* xi_out
 #define VR_R16(x) VR_R8(x) VR_R8(x)
 // Mode 0 arranges the composition the way the compiled loop is arranged (tools/isa_count.py prints the class sequence): per point a
 // cluster of conversion-class instructions (the texel unpack), then the FMAs with the bank-conflicted ones among them, the reciprocals
-// in between.  One point: 26 slow, 91 fast, 15 conflict, 2 rcp; a trip = four points (+ one more slow-class instruction: the record
-// registers' hand-over is four 64-bit moves per trip, counted with the points' 26) = 364 fast, 60 conflict, 105 slow, 8 rcp.
-#define VR_SLOW26 VR_R4(VR_SLOW4A) VR_SLOW4B VR_SLOW4A "v_cvt_f32_i32 v16, v26\n v_cvt_f32_i32 v17, v26\n"
+// in between.  One point: 27 slow, 90 fast, 15 conflict, 2 rcp; a trip = four points (+ one more slow-class instruction: tools/isa_count.py
+// counts the loop's strongly connected component, which holds the record registers' hand-over - four 64-bit moves - twice, once on the
+// path a wave takes only when it runs out of records) = 360 fast, 60 conflict, 109 slow, 8 rcp.
+#define VR_SLOW27 VR_R4(VR_SLOW4A) VR_SLOW4B VR_SLOW4A "v_cvt_f32_i32 v16, v26\n v_cvt_f32_i32 v17, v26\n v_cvt_f32_i32 v18, v26\n"
 #define VR_FAST80 VR_R4(VR_FAST8A VR_FAST8B) VR_FAST8A VR_FAST8B
 #define VR_CONF15 VR_CONF4 VR_CONF4 VR_CONF4 VR_C(2) VR_C(3) VR_C(6)
 #define VR_CONF16 VR_R4(VR_CONF4)
-#define VR_POINT_A VR_SLOW26 VR_FAST80 VR_RCP VR_F0(2) VR_F0(3) VR_F0(6) VR_F1(7) VR_F0(10) VR_F0(11) VR_F0(14) VR_F0(15) VR_F1(2) VR_F2(3) VR_F0(6) VR_CONF15 VR_RCP
+#define VR_POINT_A VR_SLOW27 VR_FAST80 VR_RCP VR_F0(2) VR_F0(3) VR_F0(6) VR_F1(7) VR_F0(10) VR_F0(11) VR_F0(14) VR_F0(15) VR_F1(2) VR_F2(3) VR_CONF15 VR_RCP
 #define VR_POINT_C "v_cvt_f32_i32 v16, v26\n" VR_POINT_A
 #define VR_TRIP VR_POINT_A VR_POINT_A VR_POINT_A VR_POINT_C
-static_assert(4 * 91 == DVO_PROBE_FAST && 4 * 15 == DVO_PROBE_CONFLICT && 4 * 26 + 1 == DVO_PROBE_SLOW && 4 * 2 == DVO_PROBE_RCP,
+static_assert(4 * 90 == DVO_PROBE_FAST && 4 * 15 == DVO_PROBE_CONFLICT && 4 * 27 + 1 == DVO_PROBE_SLOW && 4 * 2 == DVO_PROBE_RCP,
               "VR_TRIP must issue the composition the DVO_PROBE_* constants name");
 // (mode 5, the same composition in small interleaved blocks: 16 fast + 8 slow + 4 conflict = 28;   16 fast + 1 rcp = 17)
 #define VR_X1 VR_FAST8A VR_SLOW4A VR_FAST8B VR_SLOW4B VR_CONF4
 #define VR_X2 VR_FAST8A VR_FAST8B VR_RCP
-#define VR_TRIP_BLOCKS VR_R8(VR_X1) VR_R4(VR_X1) VR_X1 VR_CONF4 VR_CONF4 "v_cvt_f32_i32 v16, v26\n" VR_R4(VR_X2) VR_X2 VR_R4(VR_FAST8A VR_FAST8B) VR_FAST8A VR_F0(2) VR_F0(3) VR_F1(6) VR_F0(7) VR_RCP VR_RCP VR_RCP
+#define VR_TRIP_BLOCKS VR_R8(VR_X1) VR_R4(VR_X1) VR_X1 VR_CONF4 VR_CONF4 VR_SLOW4A "v_cvt_f32_i32 v16, v26\n" VR_R4(VR_X2) VR_X2 VR_R4(VR_FAST8A VR_FAST8B) VR_FAST8A VR_RCP VR_RCP VR_RCP
 __global__ __launch_bounds__(DVO_BLOCK) void k_valu_rate(int mode, int iterations, float* sink)
 {
     extern __shared__ float vr_lds[];                    // only sized: caps the workgroups per CU

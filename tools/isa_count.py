@@ -100,12 +100,14 @@ def kernel_facts(lib: Path = LIB, kernel: str = KERNEL) -> dict:
     ins, target = disassemble(lib, kernel)
     addr_index = {a: i for i, (a, _, _) in enumerate(ins)}
     # loops: s_cbranch_* / s_branch with a negative offset (simm16 dwords relative to the next instruction)
-    # The record loop is everything between the first target and the last source of the backward branches that stay clear of the
-    # epilogue (no LDS, no float64 instruction: those are the workgroup reduction; backward branches spanning it are block-layout
-    # artefacts or the epilogue's own little loops).  With wave-uniform loop control the compiler places the four in-bounds
-    # (phase B) blocks of a trip out of line, behind the loop's own back edge, each returning by a backward branch: the hull of
-    # all of them is one trip.
-    spans = []
+    # The record loop = the strongly connected component of the kernel's control-flow graph with the most VALU instructions among those
+    # that stay clear of the epilogue (no LDS, no float64 instruction: those are the workgroup reduction and its little loops).  With
+    # wave-uniform loop control the compiler places the four in-bounds (phase B) blocks of a trip out of line, behind the loop's own back
+    # edge, each returning by a backward branch, and it parks entry-only code (the first hand-over of the record registers) between them:
+    # the component holds exactly what one trip can execute.
+    n = len(ins)
+    leaders = {0}
+    succ_of = {}
     for i, (a, mn, ops) in enumerate(ins):
         if mn.startswith("s_cbranch") or mn == "s_branch":
             try:
@@ -114,18 +116,75 @@ def kernel_facts(lib: Path = LIB, kernel: str = KERNEL) -> dict:
                 continue
             if off >= 32768:
                 off -= 65536
-            tgt = a + 4 + 4 * off
-            if tgt <= a and tgt in addr_index:
-                j = addr_index[tgt]
-                if any(m2.startswith("ds_") or "f64" in m2 for (_, m2, _) in ins[j:i + 1]):
-                    continue
-                spans.append((j, i))
-    if not spans:
+            tgt = addr_index.get(a + 4 + 4 * off)
+            if tgt is not None:
+                leaders.add(tgt)
+                succ_of[i] = tgt
+            if i + 1 < n:
+                leaders.add(i + 1)
+        elif mn in ("s_endpgm", "s_setpc_b64"):
+            if i + 1 < n:
+                leaders.add(i + 1)
+    starts = sorted(leaders)
+    block_of = {}
+    blocks = []
+    for k, st in enumerate(starts):
+        en = (starts[k + 1] if k + 1 < len(starts) else n) - 1
+        blocks.append((st, en))
+        for i in range(st, en + 1):
+            block_of[i] = k
+    edges = {k: set() for k in range(len(blocks))}
+    for k, (st, en) in enumerate(blocks):
+        mn = ins[en][1]
+        if en in succ_of:
+            edges[k].add(block_of[succ_of[en]])
+        if mn not in ("s_branch", "s_endpgm", "s_setpc_b64") and en + 1 < n:
+            edges[k].add(block_of[en + 1])
+    # Tarjan, iterative
+    index, low, on, stack, comps, counter = {}, {}, set(), [], [], [0]
+    for root in range(len(blocks)):
+        if root in index:
+            continue
+        work = [(root, iter(sorted(edges[root])))]
+        index[root] = low[root] = counter[0]; counter[0] += 1
+        stack.append(root); on.add(root)
+        while work:
+            v, it = work[-1]
+            advanced = False
+            for w in it:
+                if w not in index:
+                    index[w] = low[w] = counter[0]; counter[0] += 1
+                    stack.append(w); on.add(w)
+                    work.append((w, iter(sorted(edges[w]))))
+                    advanced = True
+                    break
+                elif w in on:
+                    low[v] = min(low[v], index[w])
+            if advanced:
+                continue
+            work.pop()
+            if work:
+                low[work[-1][0]] = min(low[work[-1][0]], low[v])
+            if low[v] == index[v]:
+                comp = []
+                while True:
+                    w = stack.pop(); on.discard(w); comp.append(w)
+                    if w == v:
+                        break
+                comps.append(comp)
+    best = None
+    for comp in comps:
+        if len(comp) == 1 and comp[0] not in edges[comp[0]]:
+            continue
+        body_idx = [i for k in comp for i in range(blocks[k][0], blocks[k][1] + 1)]
+        if any(ins[i][1].startswith("ds_") or "f64" in ins[i][1] for i in body_idx):
+            continue
+        nv = sum(1 for i in body_idx if ins[i][1].startswith("v_"))
+        if best is None or nv > best[0]:
+            best = (nv, sorted(body_idx))
+    if best is None:
         raise RuntimeError("no loop found in {}".format(kernel))
-    lo, hi = min(j for j, _ in spans), max(i for _, i in spans)
-    if any(m2.startswith("ds_") or "f64" in m2 for (_, m2, _) in ins[lo:hi + 1]):
-        raise RuntimeError("the record loop of {} could not be told from its epilogue".format(kernel))
-    body = ins[lo:hi + 1]
+    body = [ins[i] for i in best[1]]
     cls = {"fast": 0, "fast_bank_conflict": 0, "slow": 0, "trans": 0}
     hist = {}
     n_vmem = n_salu = n_lds = 0
