@@ -160,6 +160,7 @@ struct dvo_ctx {
                                     // (tools/exp_max_groups.sh, profiles/r04_experiments.txt [9]): each workgroup pays its prologue and its
                                     // 30-term float64 reduction once, and with four streams in flight nobody waits for a launch's tail
         int target_blocks = 1024;   // DVO_TARGET_BLOCKS
+        int nt_levels = 1;          // DVO_NT_LEVELS: bit l = level l's valid-point records are loaded non-temporally (re-checked in the job: level 0 only)
         bool st_solve_phases = false;   // DVO_ST_SOLVE_PHASES: Student-t device solve with control launches between the passes
         bool no_rcache = false;         // DVO_NO_RCACHE: second Student-t scale pass recomputes the residuals
         bool ingest_unfused = false;    // DVO_INGEST_UNFUSED: separate ingest kernels for every level (tests)
@@ -362,7 +363,7 @@ int fill_reduce_params(dvo_ctx* ctx, int level, int n_pairs, int w, int h, DvoRe
     p->T = ctx->d_T;
     p->wparam = ctx->d_wparam;
     p->active = nullptr;
-    p->nt_records = (level == 0) ? 1 : 0;          // the finest level's records go around the caches (read once per launch)
+    p->nt_records = (ctx->knobs.nt_levels >> level) & 1;      // the finest level's records go around the caches (read once per launch)
     p->partials = ctx->d_partials;
     p->partials2 = nullptr;
     p->lambda0 = 0.04f;
@@ -559,6 +560,8 @@ int dvo_create(int device, int max_w, int max_h, int max_levels, int n_slots, in
         if (e && atoi(e) > 0) ctx->knobs.max_groups = atoi(e);
         e = getenv("DVO_TARGET_BLOCKS");
         if (e && atoi(e) > 0) ctx->knobs.target_blocks = atoi(e);
+        e = getenv("DVO_NT_LEVELS");
+        if (e) ctx->knobs.nt_levels = atoi(e);
         ctx->knobs.st_debug = getenv("DVO_ST_DEBUG") != nullptr;
         e = getenv("DVO_ST_TOL");
         if (e && atof(e) > 0.0) ctx->knobs.st_tol = atof(e);
