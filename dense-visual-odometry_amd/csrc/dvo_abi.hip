@@ -156,9 +156,14 @@ struct dvo_ctx {
     // solve graph bakes them in, so they must not change under it)
     struct Knobs {
         int xcd_remap = 0;          // DVO_XCD_REMAP=1: XCD-aware logical block order (measured slower)
-        int max_groups = 48;        // DVO_MAX_GROUPS: record groups (1024 records) per reduction workgroup at most.  In the job 48 beats 16 by 1.0-1.3 %
-                                    // (tools/exp_max_groups.sh, profiles/r04_experiments.txt [9]): each workgroup pays its prologue and its
-                                    // 30-term float64 reduction once, and with four streams in flight nobody waits for a launch's tail
+        int max_groups = 48;        // DVO_MAX_GROUPS: record groups (1024 records) per reduction workgroup at most.  A trade of speed against the
+                                    // length of the per-lane float32 sums (profiles/r04_experiments.txt [9], [14]; 256 VGA pairs per launch;
+                                    // error = worst increment of the reference run's 89 level-0 iterations against its float64 sums, bound 1e-5):
+                                    //   16: baseline, 1.5e-6     24: +0.5 %, 3.4e-6     32: +0.9 %, 3.9e-6     48: +1.1-1.5 %, 5.1e-6     96: 4.3e-6
+                                    // (median 3.2e-7 -> 5.5e-7: it grows like the square root of the lane's length).  Each workgroup pays its
+                                    // prologue and its 30-term float64 reduction once, and with four streams in flight nobody waits for a
+                                    // launch's tail.  A second level for the six J^T W r sums (LDS, flushed every 8 / 16 trips) brings the error
+                                    // to 2.1e-6 / 3.1e-6 and costs 1.4 % / 0.6 %: not kept.  tests: ..._production_launch_shape_...
         int target_blocks = 1024;   // DVO_TARGET_BLOCKS
         int nt_levels = 1;          // DVO_NT_LEVELS: bit l = level l's valid-point records are loaded non-temporally (re-checked in the job: level 0 only)
         bool st_solve_phases = false;   // DVO_ST_SOLVE_PHASES: Student-t device solve with control launches between the passes
