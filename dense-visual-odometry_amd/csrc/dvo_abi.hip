@@ -557,12 +557,12 @@ int dvo_create(int device, int max_w, int max_h, int max_levels, int n_slots, in
         if (e) ctx->knobs.small_max_pix = atoi(e);
         e = getenv("DVO_SMALL_THREADS");
         if (e && (atoi(e) == 256 || atoi(e) == 512 || atoi(e) == 1024)) ctx->knobs.small_threads = atoi(e);
+        e = getenv("DVO_MAX_GROUPS");
+        if (e && atoi(e) > 0) ctx->knobs.max_groups = atoi(e);
 #ifdef DVO_EXPERIMENTS
         // tuning / diagnostic knobs of experiment builds (make EXTRA=-DDVO_EXPERIMENTS): not in the product library
         e = getenv("DVO_XCD_REMAP");
         ctx->knobs.xcd_remap = (e && e[0] == '1') ? 1 : 0;
-        e = getenv("DVO_MAX_GROUPS");
-        if (e && atoi(e) > 0) ctx->knobs.max_groups = atoi(e);
         e = getenv("DVO_TARGET_BLOCKS");
         if (e && atoi(e) > 0) ctx->knobs.target_blocks = atoi(e);
         e = getenv("DVO_NT_LEVELS");

@@ -39,6 +39,10 @@
  *   DVO_INGEST_UNFUSED     separate ingest kernels at every level (the path odd image sizes take anyway)
  *   DVO_SMALL_MAX_PIX=n    pyramid levels of at most n pixels run in the persistent per-pair kernel (default 19200; 0: none)
  *   DVO_SMALL_THREADS=n    workgroup size of that kernel, 256 / 512 / 1024 (default: chosen from the batch size)
+ *   DVO_MAX_GROUPS=n       a reduction workgroup runs through at most n groups of 1024 valid-point records (default 48; matters for
+ *                          launches of more than ~16 VGA pairs).  Longer workgroups are faster and sum more records per lane in float32
+ *                          before the float64 stages: 16 gives the accuracy of small launches (worst increment error on the reference
+ *                          run's iterations 1.5e-6 instead of 5e-6 of the 1e-5 bound) for ~1.2 % of the throughput
  *   DVO_RCCL_LIB=path      RCCL library dvo_comm_create loads (default librccl.so)
  * These are tested configuration switches.  Tuning and diagnostic knobs (DVO_EXP_TAPS, DVO_SMALL_STAMPS, DVO_TARGET_BLOCKS, ...)
  * exist only in experiment builds of the library (-DDVO_EXPERIMENTS, bottom of this file).

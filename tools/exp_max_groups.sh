@@ -1,6 +1,7 @@
 #!/bin/bash
 # In-job sweep of the reduction's workgroup length (record groups per workgroup: DVO_MAX_GROUPS caps it, DVO_TARGET_BLOCKS sets the
-# number of workgroups a launch aims for); needs the experiments build (make -C dense-visual-odometry_amd/csrc experiments).
+# number of workgroups a launch aims for: experiments build only, make -C dense-visual-odometry_amd/csrc experiments; DVO_MAX_GROUPS is a
+# product knob).
 #   tools/exp_max_groups.sh "16 32 48" "1024 2048"
 MGS=${1:-"16 32 48 64"}; TBS=${2:-"1024"}
 for round in 1 2; do
