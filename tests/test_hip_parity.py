@@ -769,6 +769,30 @@ def test_levels_with_and_without_float_pattern_tap_offsets_vs_oracle():
     np.testing.assert_allclose(dev["xi"][0], est.log(), rtol=0, atol=1e-4 * np.abs(est.log()).max())       # (3e-6 on the fixture pairs is 3e-4 of their xi)
 
 
+def test_persistent_kernel_over_levels_with_and_without_float_pattern_tap_offsets(monkeypatch):
+    """The persistent per-pair kernel serves all its levels with ONE instantiation: when one of them is too large for float-pattern tap
+    offsets (2048 x 1100 at level 0) the general one, also for the smaller levels, whose geometry carries the bias.  Every level forced
+    into that kernel (DVO_SMALL_MAX_PIX) against the per-iteration launches of the default configuration."""
+    import dvo_amd
+    rng = np.random.default_rng(4243)
+    w, h, levels = 2048, 1100, 3
+    img, depth = _synthetic_frame(rng, h, w)
+    img2 = np.roll(img, (1, 2), axis=(0, 1))
+    res = []
+    for small in (None, "100000000"):
+        if small is None:
+            monkeypatch.delenv("DVO_SMALL_MAX_PIX", raising=False)
+        else:
+            monkeypatch.setenv("DVO_SMALL_MAX_PIX", small)
+        with dvo_amd.HipContext(max_w=w, max_h=h, max_levels=levels, n_slots=2, max_pairs=1) as ctx:
+            ctx.set_camera(1650.0, 1650.0, 1023.5, 549.5, 0.0, 0.0002)
+            ctx.upload_frame(0, img, depth, levels)
+            ctx.upload_frame(1, img2, depth, levels)
+            res.append(ctx.solve_batch([0], [1], levels=levels, max_iterations=2))
+    assert np.array_equal(res[0]["iters"], res[1]["iters"]) and int(res[0]["iters"][0]) == 2 * levels
+    np.testing.assert_allclose(res[1]["xi"][0], res[0]["xi"][0], rtol=0, atol=1e-5 * np.abs(res[0]["xi"]).max())
+
+
 def test_projection_division_is_bit_identical_to_ieee(hip):
     """The projection's quotient (shared refined reciprocal + ONE residual correction, no v_div_scale / v_div_fixup) against the
     compiler's IEEE division on the device and against NumPy, over the operand ranges the projection sees."""
