@@ -27,6 +27,6 @@ with dvo_amd.HipContext(max_w=W, max_h=H, max_levels=4, n_slots=B + 1, max_pairs
             ts = []
             for _ in range(20):
                 ctx.timer_start()
-                ctx.normal_equations(lvl, prev, cur, T, fetch=False) if "fetch" in ctx.normal_equations.__code__.co_varnames else ctx.normal_equations(lvl, prev, cur, T)
+                ctx.normal_equations(lvl, prev, cur, T)
                 ts.append(ctx.timer_stop())
             print("level %d, %s: %.1f us per launch (median of 20, host-mode launch incl. the sum of partials and the fetch)" % (lvl, name, 1e3 * float(np.median(ts))))
